@@ -1,0 +1,78 @@
+# Top-level build.  Everything is built in-tree so that the .so files travel to
+# the GPU box with the snapshot (they are git-ignored, not gpurun-ignored).
+#
+#   make            product libraries + tools + oracle (+ oracle/_ref when the
+#                   upstream sources are present) + the CPU test shim
+#   make product    only the product: libfpvhip.so (HIP, gfx950) and
+#                   libfpv_amd.so (host codec over the C ABI)
+
+PKG      := fusion-power-video_amd
+CSRC     := $(PKG)/csrc
+LIBDIR   := $(PKG)/lib
+BINDIR   := build/bin
+
+HIPCC    ?= /opt/rocm/bin/hipcc
+CXX      ?= g++
+ARCH     ?= gfx950
+ROCM_LIB ?= /opt/rocm/lib
+BROTLI_I ?= /opt/conda/include
+BROTLI_L ?= /usr/lib/x86_64-linux-gnu
+BROTLI   := $(BROTLI_L)/libbrotlienc.so.1 $(BROTLI_L)/libbrotlidec.so.1 $(BROTLI_L)/libbrotlicommon.so.1
+REF      ?= /root/reference
+
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -I$(CSRC) -Wall -Wno-unused-value -Wno-unused-result
+CXXFLAGS := -std=c++14 -O2 -fPIC -Iinclude -I$(CSRC) -I$(BROTLI_I) -Wall -Wextra -pthread
+
+HOST_SRC := $(CSRC)/fpv_host.cc $(CSRC)/fpv_c_api.cc
+HOST_HDR := include/fusion_power_video.h include/fpv_hip.h include/fpv_c_api.h
+
+all: product tools oracle shim refcli
+
+product: $(LIBDIR)/libfpvhip.so $(LIBDIR)/libfpv_amd.so
+
+$(LIBDIR)/libfpvhip.so: $(CSRC)/fpv_kernels.hip $(CSRC)/fpv_capi.hip $(CSRC)/fpv_kernels.h include/fpv_hip.h
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -shared $(CSRC)/fpv_kernels.hip $(CSRC)/fpv_capi.hip \
+	    -Wl,-rpath,$(ROCM_LIB) -o $@
+
+# Host codec: g++ only, calls the kernels through the C ABI of libfpvhip.so.
+$(LIBDIR)/libfpv_amd.so: $(HOST_SRC) $(HOST_HDR) $(LIBDIR)/libfpvhip.so
+	$(CXX) $(CXXFLAGS) -shared $(HOST_SRC) -L$(LIBDIR) -lfpvhip $(BROTLI) \
+	    -Wl,-rpath,'$$ORIGIN' -o $@
+
+# Our own CLI tools (written from scratch; usable on the GPU box).
+tools: $(BINDIR)/fpv_encode $(BINDIR)/fpv_decode $(BINDIR)/fpv_benchmark
+$(BINDIR)/fpv_%: tools/fpv_%.cc $(LIBDIR)/libfpv_amd.so
+	@mkdir -p $(BINDIR)
+	$(CXX) $(CXXFLAGS) $< -L$(LIBDIR) -lfpv_amd -lfpvhip \
+	    -Wl,-rpath,'$$ORIGIN/../../$(LIBDIR)' -Wl,-rpath,$(ROCM_LIB) -o $@
+
+# The upstream CLI sources compiled UNCHANGED against our header + library
+# (drop-in proof).  Only where the upstream tree is present.
+ifneq ($(wildcard $(REF)/encode.cc),)
+refcli: $(BINDIR)/ref_encode $(BINDIR)/ref_decode $(BINDIR)/ref_benchmark
+$(BINDIR)/ref_%: $(REF)/%.cc $(LIBDIR)/libfpv_amd.so
+	@mkdir -p $(BINDIR)
+	$(CXX) -std=c++14 -O2 -w -Iinclude $< -L$(LIBDIR) -lfpv_amd -lfpvhip -lpthread \
+	    -Wl,-rpath,'$$ORIGIN/../../$(LIBDIR)' -Wl,-rpath,$(ROCM_LIB) -o $@
+else
+refcli:
+	@echo "refcli: $(REF) not present, skipped"
+endif
+
+oracle:
+	$(MAKE) -C oracle REF=$(REF)
+
+# TEST-ONLY: the host codec linked against an oracle-backed stand-in for the C
+# ABI, so that the container / pipeline logic can be tested without a GPU.
+# Lives under tests/, is never loaded by the product.
+shim: tests/shim/libfpv_amd_cpushim.so
+tests/shim/libfpv_amd_cpushim.so: tests/shim/fpvhip_oracle_shim.c $(HOST_SRC) $(HOST_HDR) oracle/fpv_oracle.c
+	$(CXX) $(CXXFLAGS) -Ioracle -shared -x c tests/shim/fpvhip_oracle_shim.c -x c oracle/fpv_oracle.c \
+	    -x c++ $(HOST_SRC) $(BROTLI) -o $@
+
+clean:
+	rm -rf $(LIBDIR) build tests/shim/*.so
+	$(MAKE) -C oracle clean
+
+.PHONY: all product tools oracle shim refcli clean

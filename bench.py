@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X predictor/residual path.
+
+Workload (BASELINE.json configs[1]): 1280x800, 12-bit-in-16 synthetic plasma,
+1000 frames, encode direction.  One "step" = one pass of the forward predictor
+(split + preview + delta/CG decisions + residuals: everything Frame's ctor and
+Frame::Predict do in the reference) over the 1000-frame batch, inputs resident
+in HBM.  Brotli is not part of the hot path (it stays on the host cores).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  Multi-GPU: frame batches are sharded, one process
+per GPU, no data-path collective (weak scaling: 1000 frames per GPU).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package  # noqa: E402
+
+XS, YS, SHIFT, NFRAMES, DISTINCT = 1280, 800, 4, 1000, 64
+NPIX = XS * YS
+ALG_BYTES_PER_FRAME = 2 * NPIX + NPIX + NPIX + NPIX // 16   # 4.0625 * P
+HBM_PEAK_GBPS = 8000.0                                      # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def cpu_baseline(frames, seconds=12.0):
+    """Time the CPU checker on this host's cores over a bounded sample of the
+    same workload: Frame ctor + Frame::Predict per frame, single thread."""
+    from oracle.oracle import Oracle, Ref
+    kind = "reference" if Ref.available() else "port"
+    impl = Ref() if kind == "reference" else Oracle()
+    delta = frames[0]
+    impl.predict(frames[1], XS, YS, SHIFT, False, delta)  # warm
+    n, t0 = 0, time.perf_counter()
+    while True:
+        impl.predict(frames[n % len(frames)], XS, YS, SHIFT, False, delta)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= seconds:
+            break
+    return {"value": round(n / el, 2), "unit": "frames/s", "cores": 1, "kind": kind,
+            "sample": f"{n} frames of the same 1280x800 plasma workload, Frame ctor + Predict, 1 thread, {el:.1f} s",
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=NFRAMES)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    pkg = load_package()
+    synth = importlib.import_module("fpv_amd.synth")
+    # 64 distinct plasma frames (different phase window per rank), cycled to the batch size
+    base = synth.plasma_frames(DISTINCT, XS, YS, bits=12, seed=7, first=rank * DISTINCT)
+    n = args.frames
+    pred = pkg.Predictor(XS, YS, SHIFT, False, max_batch=n, slots=0, device=local_rank)
+    pred.set_delta_raw(base[0])
+    d_base = torch.from_numpy(base.reshape(DISTINCT, -1).view(np.int16)).to(dev)
+    idx = torch.arange(n, device=dev) % DISTINCT
+    d_frames = d_base[idx].contiguous().view(torch.uint16)
+    del d_base
+    out = pred.alloc_outputs(n)
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        pred.predict(d_frames, out=out)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pred.predict(d_frames, out=out)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # HIP-event timing on the launch stream: whole pipeline and per kernel
+    ev_ms, kernel_ms = pred.time_predict(d_frames, out, max(args.steps, 5), per_kernel=True)
+    names = ["k_stats", "k_decide", "k_apply", "k_preview_finish"]
+    dom = int(np.argmax(kernel_ms))
+    dom_s = kernel_ms[dom] / 1e3
+    achieved = n * ALG_BYTES_PER_FRAME / dom_s / 1e9
+    flags = out[3].cpu().numpy()
+
+    if rank == 0:
+        fps = world * n * args.steps / elapsed
+        res = {
+            "metric": "encode frames/sec at 1280x800x16-bit (predictor/residual stage, bit-exact vs reference)",
+            "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": "1280x800 12-bit-in-16 synthetic plasma, 1000 frames per GPU per step, shift=4, frame 0 = delta frame",
+                       "frames_per_step_per_gpu": n, "parallelism": f"frame batches sharded over {world} GPU(s), no collectives"},
+            "input_GBps": round(fps * 2 * NPIX / 1e9, 1),
+            "algorithmic_GBps_all_kernels": round(n * ALG_BYTES_PER_FRAME / (ev_ms / max(args.steps, 5) / 1e3) / 1e9, 1),
+            "kernel_ms": {k: round(v, 4) for k, v in zip(names, kernel_ms)},
+            "flags_histogram": {str(k): int(v) for k, v in zip(*np.unique(flags, return_counts=True))},
+            "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 1),
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                         "traffic": None,
+                         "algorithmic_bytes_per_launch": n * ALG_BYTES_PER_FRAME},
+        }
+        tf = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tf):
+            try:
+                res["roofline"]["traffic"] = json.load(open(tf)).get(names[dom])
+            except Exception:
+                pass
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(base)
+        print(json.dumps(res), flush=True)
+    pred.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

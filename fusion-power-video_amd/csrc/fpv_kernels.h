@@ -1,0 +1,69 @@
+// fpv_kernels.h -- launch interface between the C ABI (fpv_capi.hip) and the
+// gfx950 kernels (fpv_kernels.hip).  Internal; the public boundary is
+// include/fpv_hip.h.
+#ifndef FPV_KERNELS_H_
+#define FPV_KERNELS_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fpvhip {
+
+// Number of 256-bin histograms kept per frame by the decision stage.
+//   0: raw high bytes at stride 15                     (delta decision, cc:526-531)
+//   1/2: a / a - CG at stride 31, delta NOT applied    (CG decision,    cc:554-562)
+//   3/4: the same with the delta planes subtracted
+constexpr int kNumHists = 5;
+
+struct Geom {
+  uint32_t xs, ys, npix;        // frame
+  uint32_t pw, ph, npv;         // preview = (xs/4) x (ys/4)
+  uint32_t tile_rows, tile_px;  // forward kernel: rows per workgroup tile
+  uint32_t tiles;               // tiles per frame
+  uint32_t lds_off;             // byte offset of tile pixel 0 inside the line buffer
+  uint32_t lds_h_bytes;         // bytes of the high line buffer (16-aligned)
+  uint32_t lds_bytes;           // total dynamic LDS of the forward kernel
+  uint32_t nd, ncg;             // sample counts of the two heuristics
+  uint32_t stat_blocks;         // workgroups per frame of the stats kernel
+  uint32_t ring;                // inverse kernel: LDS ring size (power of two)
+  int32_t shift, swap;          // Frame ctor arguments (swap = big_endian on LE host)
+};
+
+// Fills every derived field from xs, ys, shift, big_endian.  Returns false (and
+// a message) when the geometry is not supported by the kernels.
+bool make_geom(uint32_t xs, uint32_t ys, int shift, int big_endian, Geom* g,
+               const char** why);
+
+struct FwdWorkspace {
+  uint32_t* hists;    // [nframes][kNumHists][256]
+  uint32_t* anylow;   // [nframes]  OR of raw low bytes
+  uint8_t* decision;  // [nframes]  bit0 delta, bit1 CG
+  uint8_t* pv_raw;    // [nframes][npv] un-predicted preview
+};
+size_t fwd_workspace_bytes(const Geom& g, uint32_t nframes);
+void carve_fwd_workspace(const Geom& g, uint32_t nframes, void* base,
+                         FwdWorkspace* ws);
+
+// Raw split of one frame into byte planes (delta frame set-up, cc:370-451).
+hipError_t launch_split(const Geom& g, const uint16_t* d_img, uint8_t* d_high,
+                        uint8_t* d_low, hipStream_t s);
+// Decoded delta image -> byte planes (decoder side, cc:337-338).
+hipError_t launch_split_decoded(const Geom& g, const uint16_t* d_img,
+                                uint8_t* d_high, uint8_t* d_low, hipStream_t s);
+
+// Forward predictor for nframes frames.  ev, when non-null, points to 5 events
+// recorded before/after each launch (timing pass).
+hipError_t launch_predict(const Geom& g, const uint16_t* d_frames,
+                          uint32_t nframes, const uint8_t* d_dhigh,
+                          const uint8_t* d_dlow, const FwdWorkspace& ws,
+                          uint8_t* d_high, uint8_t* d_low, uint8_t* d_preview,
+                          uint8_t* d_flags, hipStream_t s, hipEvent_t* ev);
+
+// Inverse predictor.  d_dhigh/d_dlow: delta planes or null.
+hipError_t launch_inverse(const Geom& g, const uint8_t* d_high,
+                          const uint8_t* d_low, const uint8_t* d_dhigh,
+                          const uint8_t* d_dlow, const uint8_t* d_flags,
+                          uint32_t nframes, uint16_t* d_frames, hipStream_t s);
+
+}  // namespace fpvhip
+#endif  // FPV_KERNELS_H_

@@ -1,0 +1,156 @@
+/*
+ * fpv_hip.h -- C ABI of the MI355X predictor/residual engine (libfpvhip.so).
+ *
+ * This is the boundary between the g++-compiled host codec
+ * (fusion_power_video.h: fpvc::Encoder / StreamingDecoder /
+ * RandomAccessDecoder / Frame) and the hipcc-compiled gfx950 kernels.  Plain
+ * pointers and sizes only; no C++ or torch types.  Every entry point names the
+ * loop(s) of the upstream reference it replaces ("cc:N" =
+ * fusion_power_video.cc line N, "h:N" = fusion_power_video.h).
+ *
+ * Conventions
+ *   - int results: 0 = ok, < 0 = error (text via fpvhip_last_error).  Nothing
+ *     throws.  There is NO CPU fallback: without a usable GPU every call fails.
+ *   - One context per (device, frame geometry).  A context is used by one host
+ *     thread at a time.  "slot" selects one of the context's independent
+ *     staging sets (pinned host buffers + device buffers + one HIP stream), so
+ *     that slot A can be in flight while the host fills or drains slot B.
+ *   - Planes are packed per frame: frame k of a batch starts at k * npix bytes
+ *     (high, low), k * npix * 2 bytes (pixels) or k * npreview bytes (preview),
+ *     npix = xs * ys, npreview = (xs / 4) * (ys / 4).
+ *   - Flags byte per frame: bit0 USE_DELTA, bit1 USE_CG, bit2 NO_LOW_BYTES
+ *     (h:68-73).
+ */
+#ifndef FPV_HIP_H_
+#define FPV_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FPVHIP_ABI_VERSION 1
+
+typedef struct fpvhip_ctx fpvhip_ctx;
+
+/* Library / device discovery. */
+int fpvhip_abi_version(void);
+/* Number of visible HIP devices, or < 0 when the runtime cannot be used. */
+int fpvhip_device_count(void);
+/* Last error text of ctx, or of the calling thread when ctx == NULL. */
+const char *fpvhip_last_error(const fpvhip_ctx *ctx);
+
+/*
+ * Create a context for xs*ys frames on `device`.
+ * shift / big_endian: as Frame's ctor (cc:370-371); shift 0..8 (0..15 when
+ * !big_endian).  max_batch: frames per submit; slots: staging sets (>= 1).
+ * xs and ys must be multiples of 4 (the reference reads out of bounds in its
+ * preview predictor otherwise, cc:575-586).  Returns NULL on failure
+ * (fpvhip_last_error(NULL)).
+ */
+fpvhip_ctx *fpvhip_create(int device, uint32_t xs, uint32_t ys, int shift,
+                          int big_endian, uint32_t max_batch, uint32_t slots);
+void fpvhip_destroy(fpvhip_ctx *ctx);
+
+/* Geometry helpers. */
+size_t fpvhip_npix(const fpvhip_ctx *ctx);
+size_t fpvhip_npreview(const fpvhip_ctx *ctx);
+uint32_t fpvhip_max_batch(const fpvhip_ctx *ctx);
+uint32_t fpvhip_slots(const fpvhip_ctx *ctx);
+
+/*
+ * Encoder side delta frame: raw pixels as handed to Encoder::Init.  Splits them
+ * on the device into the RAW high/low planes that every later frame is
+ * predicted against (replaces Frame ctor cc:370-451 for delta_frame_,
+ * cc:1097).  Synchronous.
+ */
+int fpvhip_set_delta_raw(fpvhip_ctx *ctx, const uint16_t *delta_raw);
+/*
+ * Decoder side delta frame: the DECODED delta image (uint16, as produced by
+ * DecompressImage for the delta chunk, cc:903 / cc:984).  Synchronous.
+ */
+int fpvhip_set_delta_decoded(fpvhip_ctx *ctx, const uint16_t *delta_img);
+
+/* ---- forward predictor, host-staged (Encoder pipeline) ------------------ */
+
+/* Pinned host buffer for input frame k of `slot` (npix uint16). */
+uint16_t *fpvhip_stage_in(fpvhip_ctx *ctx, uint32_t slot, uint32_t k);
+/*
+ * Queue H2D copy -> split + preview + delta/CG decisions + residuals -> D2H copy
+ * for frames 0..nframes-1 of `slot` on the slot's stream and return at once.
+ * Replaces Frame ctor + Frame::Predict (cc:370-451, cc:491-593, cc:777-785).
+ * with_delta == 0 predicts without a delta frame (the delta frame itself,
+ * cc:1099-1100).
+ */
+int fpvhip_predict_submit(fpvhip_ctx *ctx, uint32_t slot, uint32_t nframes,
+                          int with_delta);
+/*
+ * Block until the slot's batch is back in pinned host memory; returns pointers
+ * valid until the next submit on this slot.  low is meaningless (not written)
+ * when shift == 8.
+ */
+int fpvhip_predict_wait(fpvhip_ctx *ctx, uint32_t slot, const uint8_t **high,
+                        const uint8_t **low, const uint8_t **preview,
+                        const uint8_t **flags);
+
+/* ---- inverse predictor, host-staged (decoders) -------------------------- */
+
+/* Pinned host buffer for plane `which` (0 high, 1 low) of frame k of `slot`:
+ * the Brotli decoder writes straight into it. */
+uint8_t *fpvhip_stage_plane(fpvhip_ctx *ctx, uint32_t slot, uint32_t k,
+                            int which);
+/*
+ * Queue H2D -> inverse CG -> inverse delta + recombine -> D2H for nframes
+ * frames.  flags[k] is frame k's image flags byte (bit2: low plane absent =
+ * zeros).  Replaces cc:326-344 of DecompressImage.
+ */
+int fpvhip_inverse_submit(fpvhip_ctx *ctx, uint32_t slot, uint32_t nframes,
+                          const uint8_t *flags);
+int fpvhip_inverse_wait(fpvhip_ctx *ctx, uint32_t slot,
+                        const uint16_t **frames);
+
+/* ---- device-resident entry points (inputs already in HBM) --------------- */
+
+/*
+ * Same computation as predict_submit, but on caller-owned device buffers and
+ * on the caller's HIP stream (hipStream_t passed as void*; NULL = default
+ * stream).  d_frames: nframes*npix uint16; d_high/d_low: nframes*npix bytes
+ * (d_low may be NULL when shift == 8); d_preview: nframes*npreview;
+ * d_flags: nframes bytes.  nframes <= max_batch.  Asynchronous.
+ */
+int fpvhip_predict_device(fpvhip_ctx *ctx, const void *d_frames,
+                          uint32_t nframes, int with_delta, void *d_high,
+                          void *d_low, void *d_preview, void *d_flags,
+                          void *stream);
+/*
+ * Inverse on device buffers: d_high is consumed read-only, d_low may be NULL
+ * (all frames NO_LOW), d_flags nframes bytes, d_frames out nframes*npix
+ * uint16.  Asynchronous on `stream`.
+ */
+int fpvhip_inverse_device(fpvhip_ctx *ctx, const void *d_high,
+                          const void *d_low, const void *d_flags,
+                          uint32_t nframes, void *d_frames, void *stream);
+
+/*
+ * Timing helper for benchmarks: runs predict_device `iters` times back to back
+ * on `stream` bracketed by HIP events recorded on that same stream and returns
+ * the elapsed milliseconds (< 0 on error).  kernel_ms, when not NULL, receives
+ * the per-kernel average milliseconds [stats, decide, apply, preview] measured
+ * with events around each launch in a second, separate pass.
+ */
+double fpvhip_time_predict_device(fpvhip_ctx *ctx, const void *d_frames,
+                                  uint32_t nframes, int with_delta,
+                                  void *d_high, void *d_low, void *d_preview,
+                                  void *d_flags, void *stream, int iters,
+                                  double *kernel_ms);
+double fpvhip_time_inverse_device(fpvhip_ctx *ctx, const void *d_high,
+                                  const void *d_low, const void *d_flags,
+                                  uint32_t nframes, void *d_frames,
+                                  void *stream, int iters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FPV_HIP_H_ */

@@ -1,0 +1,44 @@
+"""pytest configuration: the `gpu` marker and loaders for the hyphenated package."""
+import importlib.util
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+def load_package():
+    """Import fusion-power-video_amd/ under the module name `fpv_amd`."""
+    if "fpv_amd" in sys.modules:
+        return sys.modules["fpv_amd"]
+    path = os.path.join(ROOT, "fusion-power-video_amd")
+    spec = importlib.util.spec_from_file_location(
+        "fpv_amd", os.path.join(path, "__init__.py"), submodule_search_locations=[path])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["fpv_amd"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.fixture(scope="session")
+def fpv():
+    return load_package()
+
+
+@pytest.fixture(scope="session")
+def synth(fpv):
+    import importlib
+    return importlib.import_module("fpv_amd.synth")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle.oracle import Oracle
+    return Oracle()

@@ -1,0 +1,63 @@
+"""GPU parity of the forward / inverse predictor kernels (through the C ABI,
+device-resident entry points) against the CPU oracle on the same inputs."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_case(fpv, oracle, frames, xs, ys, shift, be, delta_raw):
+    import torch
+    n = frames.shape[0]
+    p = fpv.Predictor(xs, ys, shift, be, max_batch=max(n, 1))
+    if delta_raw is not None:
+        p.set_delta_raw(delta_raw)
+    d = torch.from_numpy(frames.reshape(n, -1).view(np.int16)).cuda().view(torch.uint16)
+    high, low, pv, flags = p.predict(d, with_delta=delta_raw is not None)
+    torch.cuda.synchronize()
+    high, low, pv, flags = (t.cpu().numpy() for t in (high, low, pv, flags))
+    for k in range(n):
+        eh, el, ep, ef = oracle.predict(frames[k], xs, ys, shift, be, delta_raw)
+        assert flags[k] == ef, f"frame {k}: flags {flags[k]} != {ef}"
+        assert np.array_equal(high[k], eh), f"frame {k}: high plane differs"
+        if shift != 8:
+            assert np.array_equal(low[k], el), f"frame {k}: low plane differs"
+        assert np.array_equal(pv[k], ep), f"frame {k}: preview differs"
+    # inverse: back to the (shifted) pixels
+    if delta_raw is not None:
+        dh, dl, _ = oracle.split(delta_raw, shift, be)
+        p.set_delta_decoded((dh.astype(np.uint16) << 8) | dl)
+    th, tl, tf = (torch.from_numpy(a).cuda() for a in (high, low, flags))
+    rec = p.inverse(th, tl, tf)
+    torch.cuda.synchronize()
+    rec = rec.cpu().view(torch.int16).numpy().view(np.uint16)
+    for k in range(n):
+        delta16 = None if delta_raw is None else ((dh.astype(np.uint16) << 8) | dl)
+        exp = oracle.inverse(high[k], None if flags[k] & 4 else low[k], delta16, xs, ys, int(flags[k]))
+        assert np.array_equal(rec[k], exp), f"frame {k}: inverse differs"
+    p.close()
+    return flags
+
+
+@pytest.mark.parametrize("shift,be", [(0, False), (4, False), (0, True), (4, True), (8, False), (8, True)])
+def test_noise_256(fpv, synth, oracle, shift, be):
+    fr = synth.noise_frames(8, 256, 256, seed=1)
+    _run_case(fpv, oracle, fr, 256, 256, shift, be, fr[0])
+
+
+def test_plasma_1280x800(fpv, synth, oracle):
+    fr = synth.plasma_frames(4, 1280, 800, bits=12)
+    flags = _run_case(fpv, oracle, fr, 1280, 800, 4, False, fr[0])
+    assert list(flags[1:]) == [3, 3, 3]
+
+
+def test_no_delta_frame(fpv, synth, oracle):
+    fr = synth.plasma_frames(2, 1280, 800, bits=12)
+    _run_case(fpv, oracle, fr, 1280, 800, 4, False, None)
+
+
+@pytest.mark.parametrize("xs,ys", [(64, 48), (4, 4), (8, 4), (4096, 8), (1920, 1080), (36, 20)])
+def test_shapes(fpv, synth, oracle, xs, ys):
+    fr = synth.noise_frames(3, xs, ys, seed=3)
+    fr[1] = (fr[1] >> 9) + 3000          # smooth-ish: exercises the CG-on branch
+    _run_case(fpv, oracle, fr, xs, ys, 0, False, fr[0])

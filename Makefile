@@ -23,8 +23,8 @@ REF      ?= /root/reference
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -I$(CSRC) -Wall -Wno-unused-value -Wno-unused-result
 CXXFLAGS := -std=c++14 -O2 -fPIC -Iinclude -I$(CSRC) -I$(BROTLI_I) -Wall -Wextra -pthread
 
-HOST_SRC := $(CSRC)/fpv_host.cc $(CSRC)/fpv_c_api.cc
-HOST_HDR := include/fusion_power_video.h include/fpv_hip.h include/fpv_c_api.h
+HOST_SRC := $(CSRC)/fpv_host.cc $(CSRC)/fpv_decoders.cc $(CSRC)/fpv_c_api.cc
+HOST_HDR := include/fusion_power_video.h include/fpv_hip.h include/fpv_c_api.h $(CSRC)/fpv_host_internal.h
 
 all: product tools oracle shim refcli
 
@@ -51,7 +51,14 @@ $(BINDIR)/fpv_%: tools/fpv_%.cc $(LIBDIR)/libfpv_amd.so
 # (drop-in proof).  Only where the upstream tree is present.
 ifneq ($(wildcard $(REF)/encode.cc),)
 refcli: $(BINDIR)/ref_encode $(BINDIR)/ref_decode $(BINDIR)/ref_benchmark
-$(BINDIR)/ref_%: $(REF)/%.cc $(LIBDIR)/libfpv_amd.so
+# The sources are reached through symlinks in build/refsrc so that their
+# `#include "fusion_power_video.h"` finds OUR header (-Iinclude) and not the
+# upstream one sitting next to them.
+.SECONDARY:
+build/refsrc/%.cc: $(REF)/%.cc
+	@mkdir -p build/refsrc
+	ln -sf $< $@
+$(BINDIR)/ref_%: build/refsrc/%.cc $(LIBDIR)/libfpv_amd.so include/fusion_power_video.h
 	@mkdir -p $(BINDIR)
 	$(CXX) -std=c++14 -O2 -w -Iinclude $< -L$(LIBDIR) -lfpv_amd -lfpvhip -lpthread \
 	    -Wl,-rpath,'$$ORIGIN/../../$(LIBDIR)' -Wl,-rpath,$(ROCM_LIB) -o $@
@@ -67,12 +74,16 @@ oracle:
 # ABI, so that the container / pipeline logic can be tested without a GPU.
 # Lives under tests/, is never loaded by the product.
 shim: tests/shim/libfpv_amd_cpushim.so
-tests/shim/libfpv_amd_cpushim.so: tests/shim/fpvhip_oracle_shim.c $(HOST_SRC) $(HOST_HDR) oracle/fpv_oracle.c
-	$(CXX) $(CXXFLAGS) -Ioracle -shared -x c tests/shim/fpvhip_oracle_shim.c -x c oracle/fpv_oracle.c \
-	    -x c++ $(HOST_SRC) $(BROTLI) -o $@
+tests/shim/fpvhip_oracle_shim.o: tests/shim/fpvhip_oracle_shim.c include/fpv_hip.h oracle/fpv_oracle.h
+	gcc -std=c99 -O2 -fPIC -Wall -Wextra -Iinclude -Ioracle -c $< -o $@
+tests/shim/fpv_oracle.o: oracle/fpv_oracle.c oracle/fpv_oracle.h
+	gcc -std=c99 -O2 -fPIC -Wall -Wextra -Ioracle -I$(BROTLI_I) -c $< -o $@
+tests/shim/libfpv_amd_cpushim.so: tests/shim/fpvhip_oracle_shim.o tests/shim/fpv_oracle.o $(HOST_SRC) $(HOST_HDR)
+	$(CXX) $(CXXFLAGS) -shared $(HOST_SRC) tests/shim/fpvhip_oracle_shim.o tests/shim/fpv_oracle.o \
+	    $(BROTLI) -o $@
 
 clean:
-	rm -rf $(LIBDIR) build tests/shim/*.so
+	rm -rf $(LIBDIR) build tests/shim/*.so tests/shim/*.o
 	$(MAKE) -C oracle clean
 
 .PHONY: all product tools oracle shim refcli clean

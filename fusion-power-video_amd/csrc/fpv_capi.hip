@@ -93,8 +93,10 @@ int alloc_slot(fpvhip_ctx* c, Slot* s) {
   HIPOK(c, hipMalloc(reinterpret_cast<void**>(&s->d_low), B * np));
   HIPOK(c, hipMalloc(reinterpret_cast<void**>(&s->d_pv), B * nv));
   HIPOK(c, hipMalloc(reinterpret_cast<void**>(&s->d_flags), B));
-  HIPOK(c, hipMalloc(&s->d_ws, fpvhip::fwd_workspace_bytes(c->g, c->max_batch)));
-  fpvhip::carve_fwd_workspace(c->g, c->max_batch, s->d_ws, &s->ws);
+  if (c->g.fwd_ok) {
+    HIPOK(c, hipMalloc(&s->d_ws, fpvhip::fwd_workspace_bytes(c->g, c->max_batch)));
+    fpvhip::carve_fwd_workspace(c->g, c->max_batch, s->d_ws, &s->ws);
+  }
   return 0;
 }
 
@@ -135,14 +137,8 @@ const char* fpvhip_last_error(const fpvhip_ctx* ctx) {
   return ctx ? ctx->err : g_err;
 }
 
-fpvhip_ctx* fpvhip_create(int device, uint32_t xs, uint32_t ys, int shift,
-                          int big_endian, uint32_t max_batch, uint32_t slots) {
-  Geom g;
-  const char* why = "";
-  if (!fpvhip::make_geom(xs, ys, shift, big_endian, &g, &why)) {
-    fail(nullptr, "unsupported geometry %ux%u shift %d: %s", xs, ys, shift, why);
-    return nullptr;
-  }
+static fpvhip_ctx* create_impl(int device, const Geom& g, uint32_t max_batch,
+                               uint32_t slots) {
   if (max_batch == 0 || max_batch > 65535) {
     fail(nullptr, "max_batch must be 1..65535");
     return nullptr;
@@ -161,26 +157,49 @@ fpvhip_ctx* fpvhip_create(int device, uint32_t xs, uint32_t ys, int shift,
   c->device = device;
   c->g = g;
   c->max_batch = max_batch;
-  auto bail = [&]() -> fpvhip_ctx* {
-    snprintf(g_err, sizeof g_err, "%s", c->err);
-    fpvhip_destroy(c);
-    return nullptr;
-  };
   auto setup = [&]() -> int {
     HIPOK(c, hipSetDevice(device));
     HIPOK(c, hipMalloc(reinterpret_cast<void**>(&c->d_dhigh), g.npix));
     HIPOK(c, hipMalloc(reinterpret_cast<void**>(&c->d_dlow), g.npix));
     HIPOK(c, hipMalloc(reinterpret_cast<void**>(&c->d_dtmp), (size_t)g.npix * 2));
-    HIPOK(c, hipMalloc(&c->d_ws, fpvhip::fwd_workspace_bytes(g, max_batch)));
-    fpvhip::carve_fwd_workspace(g, max_batch, c->d_ws, &c->ws);
+    if (g.fwd_ok) {
+      HIPOK(c, hipMalloc(&c->d_ws, fpvhip::fwd_workspace_bytes(g, max_batch)));
+      fpvhip::carve_fwd_workspace(g, max_batch, c->d_ws, &c->ws);
+    }
     for (auto& e : c->ev) HIPOK(c, hipEventCreate(&e));
     c->slots.resize(slots);
     for (auto& s : c->slots)
       if (alloc_slot(c, &s)) return -1;
     return 0;
   };
-  if (setup()) return bail();
+  if (setup()) {
+    snprintf(g_err, sizeof g_err, "%s", c->err);
+    fpvhip_destroy(c);
+    return nullptr;
+  }
   return c;
+}
+
+fpvhip_ctx* fpvhip_create(int device, uint32_t xs, uint32_t ys, int shift,
+                          int big_endian, uint32_t max_batch, uint32_t slots) {
+  Geom g;
+  const char* why = "";
+  if (!fpvhip::make_geom(xs, ys, shift, big_endian, &g, &why)) {
+    fail(nullptr, "unsupported geometry %ux%u shift %d: %s", xs, ys, shift, why);
+    return nullptr;
+  }
+  return create_impl(device, g, max_batch, slots);
+}
+
+fpvhip_ctx* fpvhip_create_decoder(int device, uint32_t xs, uint32_t ys,
+                                  uint32_t max_batch, uint32_t slots) {
+  Geom g;
+  const char* why = "";
+  if (!fpvhip::make_geom_decoder(xs, ys, &g, &why)) {
+    fail(nullptr, "unsupported geometry %ux%u: %s", xs, ys, why);
+    return nullptr;
+  }
+  return create_impl(device, g, max_batch, slots);
 }
 
 void fpvhip_destroy(fpvhip_ctx* c) {
@@ -199,6 +218,7 @@ uint32_t fpvhip_slots(const fpvhip_ctx* c) { return c ? (uint32_t)c->slots.size(
 
 int fpvhip_set_delta_raw(fpvhip_ctx* c, const uint16_t* delta_raw) {
   if (!c || !delta_raw) return fail(c, "null argument");
+  if (!c->g.fwd_ok) return fail(c, "decoder-only context");
   HIPOK(c, hipSetDevice(c->device));
   HIPOK(c, hipMemcpy(c->d_dtmp, delta_raw, (size_t)c->g.npix * 2, hipMemcpyHostToDevice));
   HIPOK(c, fpvhip::launch_split(c->g, c->d_dtmp, c->d_dhigh, c->d_dlow, nullptr));
@@ -217,6 +237,18 @@ int fpvhip_set_delta_decoded(fpvhip_ctx* c, const uint16_t* delta_img) {
   return 0;
 }
 
+int fpvhip_set_delta_planes(fpvhip_ctx* c, const uint8_t* high, const uint8_t* low) {
+  if (!c || !high) return fail(c, "null argument");
+  HIPOK(c, hipSetDevice(c->device));
+  HIPOK(c, hipMemcpy(c->d_dhigh, high, c->g.npix, hipMemcpyHostToDevice));
+  if (low)
+    HIPOK(c, hipMemcpy(c->d_dlow, low, c->g.npix, hipMemcpyHostToDevice));
+  else
+    HIPOK(c, hipMemset(c->d_dlow, 0, c->g.npix));
+  c->have_delta = true;
+  return 0;
+}
+
 uint16_t* fpvhip_stage_in(fpvhip_ctx* c, uint32_t slot, uint32_t k) {
   if (check_slot(c, slot) || k >= c->max_batch) return nullptr;
   return c->slots[slot].h_pix + (size_t)k * c->g.npix;
@@ -227,6 +259,7 @@ int fpvhip_predict_submit(fpvhip_ctx* c, uint32_t slot, uint32_t nframes,
   if (check_slot(c, slot)) return -1;
   if (nframes == 0 || nframes > c->max_batch) return fail(c, "bad nframes %u", nframes);
   if (with_delta && !c->have_delta) return fail(c, "delta frame not set");
+  if (!c->g.fwd_ok) return fail(c, "decoder-only context");
   Slot& s = c->slots[slot];
   const size_t np = c->g.npix, nv = c->g.npv;
   HIPOK(c, hipSetDevice(c->device));
@@ -307,6 +340,7 @@ int fpvhip_predict_device(fpvhip_ctx* c, const void* d_frames, uint32_t nframes,
                           int with_delta, void* d_high, void* d_low,
                           void* d_preview, void* d_flags, void* stream) {
   if (!c) return fail(nullptr, "null context");
+  if (!c->g.fwd_ok) return fail(c, "decoder-only context");
   if (!d_frames || !d_high || !d_preview || !d_flags || (!d_low && c->g.shift != 8))
     return fail(c, "null device pointer");
   if (nframes == 0 || nframes > c->max_batch) return fail(c, "bad nframes %u", nframes);
@@ -340,7 +374,7 @@ double fpvhip_time_predict_device(fpvhip_ctx* c, const void* d_frames,
                                   uint32_t nframes, int with_delta, void* d_high,
                                   void* d_low, void* d_preview, void* d_flags,
                                   void* stream, int iters, double* kernel_ms) {
-  if (!c || iters <= 0) { fail(c, "bad arguments"); return -1.0; }
+  if (!c || iters <= 0 || !c->g.fwd_ok) { fail(c, "bad arguments"); return -1.0; }
   hipStream_t st = static_cast<hipStream_t>(stream);
   auto run = [&](hipEvent_t* ev) {
     return fpvhip::launch_predict(

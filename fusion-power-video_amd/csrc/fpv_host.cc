@@ -1,0 +1,529 @@
+// fpv_host.cc -- host side of the MI355X codec: the fusion_power_video.h API
+// (Encoder, StreamingDecoder, RandomAccessDecoder, UnextractFrame) implemented
+// as a batch pipeline over the C ABI of fpv_hip.h.
+//
+//   CompressFrame -> pinned staging slot -> [GPU: H2D, predictor kernels, D2H on
+//   the slot's stream] -> dispatcher thread -> Brotli worker pool -> in-order
+//   emitter -> user callback
+//
+// What runs where: every per-pixel loop of the reference's Frame ctor,
+// Frame::Predict and DecompressImage (cc:326-344, 370-593) runs on the GPU.
+// This file keeps only what the reference also does outside those loops: the
+// container format (cc:30-155), Brotli calls (cc:186-214, 643-688), queueing
+// and callback ordering (cc:1076-1230).  No CPU fallback exists.
+#include <brotli/decode.h>
+#include <brotli/encode.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <thread>
+
+#include "fpv_hip.h"
+#include "fpv_host_internal.h"
+#include "fusion_power_video.h"
+
+namespace fpvc {
+namespace internal {
+
+// ------------------------------------------------------------ diagnostics --
+
+// Decoders report failures like the reference does (cc:172-178): one stderr
+// line with the place, and a false result.
+bool Failure(const char* file, int line, const char* msg) {
+  const char* base = strrchr(file, '/');
+  fprintf(stderr, "failure at: %s:%d", base ? base + 1 : file, line);
+  if (msg && *msg) fprintf(stderr, ": %s", msg);
+  fputc('\n', stderr);
+  return false;
+}
+
+// The encoder API is void everywhere (cc:1086-1157): a GPU failure cannot be
+// reported to the caller, and silently producing nothing would corrupt the
+// stream.  Fail loudly.
+void Fatal(const char* what, const char* detail) {
+  fprintf(stderr, "fpv-mi355x: fatal: %s: %s\n", what, detail ? detail : "");
+  fprintf(stderr, "fpv-mi355x: the predictor stage has no CPU fallback; a usable "
+                  "MI355X and libfpvhip.so are required\n");
+  abort();
+}
+
+// -------------------------------------------------------------- LE helpers --
+
+uint32_t Load32(const uint8_t* p) {
+  return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24;
+}
+uint64_t Load64(const uint8_t* p) {
+  return (uint64_t)Load32(p) | (uint64_t)Load32(p + 4) << 32;
+}
+void Store32(uint32_t v, uint8_t* p) {
+  for (int i = 0; i < 4; i++) p[i] = (uint8_t)(v >> (8 * i));
+}
+void Store64(uint64_t v, uint8_t* p) {
+  for (int i = 0; i < 8; i++) p[i] = (uint8_t)(v >> (8 * i));
+}
+void Append32(uint32_t v, std::vector<uint8_t>* out) {
+  uint8_t b[4];
+  Store32(v, b);
+  out->insert(out->end(), b, b + 4);
+}
+bool OutOfRange(size_t pos, size_t width, size_t size) {
+  return pos > size || size - pos < width;
+}
+
+// ------------------------------------------------------------------ Brotli --
+
+// cc:653: quality 1, default window (22), default mode; one shot per plane.
+// Appends to *out.  The reference first tries a plane-sized output buffer for
+// the low plane and retries with the maximum (cc:661-673); the bytes are the
+// same as this single maximum-size call.
+bool BrotliAppend(const uint8_t* in, size_t n, std::vector<uint8_t>* out) {
+  size_t cap = BrotliEncoderMaxCompressedSize(n);
+  if (cap == 0) cap = n + 1024;
+  size_t at = out->size();
+  out->resize(at + cap);
+  size_t sz = cap;
+  if (!BrotliEncoderCompress(1, BROTLI_DEFAULT_WINDOW, BROTLI_DEFAULT_MODE, n, in,
+                             &sz, out->data() + at)) {
+    out->resize(at);
+    return false;
+  }
+  out->resize(at + sz);
+  return true;
+}
+
+// cc:186-214: decodes ONE stream starting at in[*pos] straight into dst (cap
+// bytes); *pos ends up behind the stream, *got = bytes produced.  A stream
+// longer than cap stops with got == cap and returns false.
+bool BrotliInto(const uint8_t* in, size_t size, size_t* pos, uint8_t* dst,
+                size_t cap, size_t* got) {
+  BrotliDecoderState* st = BrotliDecoderCreateInstance(nullptr, nullptr, nullptr);
+  if (!st) return false;
+  size_t avail_in = size - *pos, avail_out = cap;
+  const uint8_t* next_in = in + *pos;
+  uint8_t* next_out = dst;
+  BrotliDecoderResult r = BrotliDecoderDecompressStream(st, &avail_in, &next_in,
+                                                        &avail_out, &next_out, nullptr);
+  BrotliDecoderDestroyInstance(st);
+  *pos = size - avail_in;
+  *got = cap - avail_out;
+  return r == BROTLI_DECODER_RESULT_SUCCESS;
+}
+
+// ----------------------------------------------------------------- devices --
+
+// GPUs used by the encoder: FPV_DEVICES="0,2,3" or every visible device.
+std::vector<int> DeviceList() {
+  int n = fpvhip_device_count();
+  if (n <= 0) Fatal("no usable GPU", fpvhip_last_error(nullptr));
+  std::vector<int> devs;
+  if (const char* env = getenv("FPV_DEVICES")) {
+    for (const char* p = env; *p;) {
+      char* end;
+      long d = strtol(p, &end, 10);
+      if (end == p) break;
+      if (d >= 0 && d < n) devs.push_back((int)d);
+      p = *end ? end + 1 : end;
+    }
+  }
+  if (devs.empty())
+    for (int d = 0; d < n; d++) devs.push_back(d);
+  return devs;
+}
+
+size_t EnvSize(const char* name, size_t dflt) {
+  const char* e = getenv(name);
+  if (!e || !*e) return dflt;
+  long long v = atoll(e);
+  return v > 0 ? (size_t)v : dflt;
+}
+
+// One frame chunk (OutputFull, cc:830-846) from predicted planes:
+//   u32 total | 0x00 | u32 (1 + len(preview stream)) | (flags & CG) | NO_LOW |
+//   brotli(preview) | flags | [brotli(low)] | brotli(high)
+void BuildFrameChunk(const uint8_t* high, const uint8_t* low, const uint8_t* preview,
+                     uint8_t flags, size_t npix, size_t npv,
+                     std::vector<uint8_t>* out) {
+  out->clear();
+  out->reserve(npix + npix / 2);
+  out->resize(9);
+  out->push_back((uint8_t)((flags & USE_CG) | NO_LOW_BYTES));  // cc:842
+  if (!BrotliAppend(preview, npv, out)) Fatal("Brotli", "preview plane");
+  Store32((uint32_t)(out->size() - 9), out->data() + 5);  // preview stream + its flags byte
+  out->push_back(flags);                                      // cc:825
+  if (!(flags & NO_LOW_BYTES) && !BrotliAppend(low, npix, out)) Fatal("Brotli", "low plane");
+  if (!BrotliAppend(high, npix, out)) Fatal("Brotli", "high plane");
+  Store32((uint32_t)out->size(), out->data());
+  (*out)[4] = 0;  // chunk flag: ordinary frame (cc:840)
+}
+
+// Image core only (OutputCore, cc:820-828), appended.
+void AppendCore(const uint8_t* high, const uint8_t* low, uint8_t flags, size_t npix,
+                std::vector<uint8_t>* out) {
+  out->push_back(flags);
+  if (!(flags & NO_LOW_BYTES) && !BrotliAppend(low, npix, out)) Fatal("Brotli", "low plane");
+  if (!BrotliAppend(high, npix, out)) Fatal("Brotli", "high plane");
+}
+
+}  // namespace internal
+
+using namespace internal;
+
+// cc:850-862 -- file-format repacking outside the codec; plain host loop.
+void UnextractFrame(const uint16_t* img, size_t xsize, size_t ysize, int shift,
+                    bool big_endian, uint8_t* out) {
+  const size_t n = xsize * ysize;
+  const int lo = big_endian ? 1 : 0, hi = 1 - lo;
+  for (size_t i = 0; i < n; i++) {
+    const uint16_t u = (uint16_t)(img[i] >> shift);
+    out[2 * i + lo] = (uint8_t)(u & 0xff);
+    out[2 * i + hi] = (uint8_t)(u >> 8);
+  }
+}
+
+// ================================================================= Encoder ==
+
+struct Encoder::Impl {
+  struct Batch {
+    int dev = 0;            // index into ctxs
+    uint32_t slot = 0;
+    uint32_t n = 0;         // frames staged
+    size_t first_id = 0;
+    std::vector<Callback> cbs;
+    std::vector<void*> payloads;
+    // filled by the dispatcher after the GPU batch is back
+    const uint8_t *high = nullptr, *low = nullptr, *pv = nullptr, *flags = nullptr;
+    std::vector<std::vector<uint8_t>> chunks;
+    std::vector<char> done;
+    uint32_t emitted = 0;
+  };
+  struct Task { Batch* b; uint32_t k; };
+
+  const size_t num_threads;
+  const int shift;
+  const bool big_endian;
+  size_t batch_promised = 1;   // frames per batch announced through MaxQueued()
+  size_t batch = 1;            // effective (after Init, bounded by bytes)
+  size_t max_queued = 1;
+  uint32_t slots_per_dev = 3;
+
+  size_t xs = 0, ys = 0, npix = 0, npv = 0;
+  bool initialized = false, finished = false;
+  std::vector<int> devices;
+  std::vector<fpvhip_ctx*> ctxs;
+
+  std::mutex m;
+  std::condition_variable cv_producer;   // slot freed / in-flight count dropped
+  std::condition_variable cv_dispatch;   // batch submitted / stop
+  std::condition_variable cv_work;       // tasks available / stop
+  bool stop = false;
+
+  std::vector<std::vector<char>> slot_busy;   // [dev][slot]
+  size_t next_dev = 0;
+  Batch* cur = nullptr;                       // batch being filled by the producer
+  std::chrono::steady_clock::time_point cur_touched;
+  std::deque<Batch*> gpu_q;                   // submitted, waiting for the GPU
+  std::deque<Task> work_q;
+  std::deque<Batch*> emit_q;                  // submission order
+  size_t inflight = 0;                        // accepted, not yet emitted
+  size_t next_id = 0;
+
+  std::vector<uint64_t> offsets;              // frame index (cc:1180)
+  uint64_t bytes_written = 0;
+
+  std::thread dispatcher;
+  std::vector<std::thread> workers;
+
+  Impl(size_t threads, int s, bool be) : num_threads(threads), shift(s), big_endian(be) {
+    if (threads == 0) {
+      batch_promised = 1;
+      max_queued = 1;  // cc:1176
+    } else {
+      size_t b = EnvSize("FPV_BATCH", 0);
+      if (b == 0) b = std::min<size_t>(128, std::max<size_t>(8, (threads + 1) / 2));
+      batch_promised = b;
+      max_queued = slots_per_dev * b;
+    }
+  }
+
+  void CheckHip(int rc, fpvhip_ctx* c, const char* what) {
+    if (rc != 0) Fatal(what, fpvhip_last_error(c));
+  }
+
+  // --- producer side (caller thread, m held) ---
+  void SubmitLocked(Batch* b) {
+    CheckHip(fpvhip_predict_submit(ctxs[b->dev], b->slot, b->n, 1), ctxs[b->dev],
+             "fpvhip_predict_submit");
+    gpu_q.push_back(b);
+    emit_q.push_back(b);
+    cv_dispatch.notify_one();
+  }
+
+  Batch* OpenBatchLocked(std::unique_lock<std::mutex>& l) {
+    for (;;) {
+      for (size_t t = 0; t < devices.size(); t++) {
+        size_t d = (next_dev + t) % devices.size();
+        for (uint32_t s = 0; s < slots_per_dev; s++) {
+          if (!slot_busy[d][s]) {
+            slot_busy[d][s] = 1;
+            next_dev = (d + 1) % devices.size();  // batch b -> GPU b mod G
+            Batch* b = new Batch();
+            b->dev = (int)d;
+            b->slot = s;
+            b->first_id = next_id;
+            return b;
+          }
+        }
+      }
+      cv_producer.wait(l);
+    }
+  }
+
+  // --- dispatcher: waits for GPU batches, fans out Brotli tasks, and flushes a
+  // partially filled batch when the producer goes quiet ---
+  void DispatchLoop() {
+    std::unique_lock<std::mutex> l(m);
+    for (;;) {
+      if (gpu_q.empty()) {
+        if (stop) return;
+        cv_dispatch.wait_for(l, std::chrono::milliseconds(2));
+        if (gpu_q.empty() && cur && cur->n > 0 &&
+            std::chrono::steady_clock::now() - cur_touched > std::chrono::milliseconds(2)) {
+          Batch* b = cur;
+          cur = nullptr;
+          SubmitLocked(b);
+        }
+        continue;
+      }
+      Batch* b = gpu_q.front();
+      gpu_q.pop_front();
+      l.unlock();
+      CheckHip(fpvhip_predict_wait(ctxs[b->dev], b->slot, &b->high, &b->low, &b->pv, &b->flags),
+               ctxs[b->dev], "fpvhip_predict_wait");
+      l.lock();
+      b->chunks.resize(b->n);
+      b->done.assign(b->n, 0);
+      for (uint32_t k = 0; k < b->n; k++) work_q.push_back(Task{b, k});
+      cv_work.notify_all();
+    }
+  }
+
+  void CompressTask(const Task& t, std::vector<uint8_t>* chunk) {
+    const Batch* b = t.b;
+    BuildFrameChunk(b->high + (size_t)t.k * npix, b->low + (size_t)t.k * npix,
+                    b->pv + (size_t)t.k * npv, b->flags[t.k], npix, npv, chunk);
+  }
+
+  // Emits every finished frame at the head of the order.  Called with m held;
+  // the lock is dropped around each user callback, and `emitting` keeps the
+  // callbacks mutually exclusive and in submission order (cc:1217-1224).
+  bool emitting = false;
+  void DrainLocked(std::unique_lock<std::mutex>& l) {
+    if (emitting) return;
+    emitting = true;
+    while (!emit_q.empty()) {
+      Batch* b = emit_q.front();
+      if (b->done.empty()) break;  // GPU batch not back yet
+      if (b->emitted < b->n) {
+        const uint32_t k = b->emitted;
+        if (!b->done[k]) break;
+        std::vector<uint8_t> c;
+        c.swap(b->chunks[k]);
+        offsets.push_back(bytes_written);  // cc:1180-1182
+        bytes_written += c.size();
+        l.unlock();
+        b->cbs[k](c.data(), c.size(), b->payloads[k]);
+        l.lock();
+        b->emitted++;
+        inflight--;
+        cv_producer.notify_all();
+        continue;
+      }
+      emit_q.pop_front();
+      slot_busy[b->dev][b->slot] = 0;
+      delete b;
+      cv_producer.notify_all();
+    }
+    emitting = false;
+  }
+
+  void WorkLoop() {
+    std::unique_lock<std::mutex> l(m);
+    for (;;) {
+      cv_work.wait(l, [this] { return stop || !work_q.empty(); });
+      if (work_q.empty()) {
+        if (stop) return;
+        continue;
+      }
+      Task t = work_q.front();
+      work_q.pop_front();
+      l.unlock();
+      std::vector<uint8_t> chunk;
+      CompressTask(t, &chunk);
+      l.lock();
+      t.b->chunks[t.k].swap(chunk);
+      t.b->done[t.k] = 1;
+      DrainLocked(l);
+    }
+  }
+
+  void StartThreads() {
+    dispatcher = std::thread(&Impl::DispatchLoop, this);
+    for (size_t i = 0; i < num_threads; i++) workers.emplace_back(&Impl::WorkLoop, this);
+  }
+
+  void StopThreads() {
+    {
+      std::lock_guard<std::mutex> l(m);
+      stop = true;
+    }
+    cv_dispatch.notify_all();
+    cv_work.notify_all();
+    if (dispatcher.joinable()) dispatcher.join();
+    for (auto& w : workers) w.join();
+    workers.clear();
+  }
+
+  void ReleaseContexts() {
+    for (size_t i = 0; i < ctxs.size(); i++) ReleaseEncoderCtx(ctxs[i]);
+    ctxs.clear();
+  }
+};
+
+Encoder::Encoder(size_t num_threads, int shift_to_left_align, bool big_endian)
+    : impl_(new Impl(num_threads, shift_to_left_align, big_endian)) {}
+
+Encoder::~Encoder() {
+  if (!impl_) return;
+  if (impl_->initialized && !impl_->finished) {
+    // The upstream class leaks its threads here; drain quietly instead.
+    Finish([](const uint8_t*, size_t, void*) {}, nullptr);
+  }
+}
+
+size_t Encoder::MaxQueued() const { return impl_->max_queued; }
+
+void Encoder::Init(const uint16_t* delta_frame, size_t xsize, size_t ysize,
+                   Callback callback, void* payload) {
+  Impl& s = *impl_;
+  if (s.initialized) Fatal("Encoder::Init", "called twice");
+  s.xs = xsize;
+  s.ys = ysize;
+  s.npix = xsize * ysize;
+  s.npv = (xsize / 4) * (ysize / 4);
+  // bound the pinned staging memory per slot
+  const size_t cap_bytes = EnvSize("FPV_BATCH_BYTES", (size_t)256 << 20);
+  s.batch = std::max<size_t>(1, std::min(s.batch_promised, cap_bytes / std::max<size_t>(1, 2 * s.npix)));
+  if (s.num_threads == 0) s.slots_per_dev = 1;
+  s.devices = DeviceList();
+  if (s.num_threads == 0) s.devices.resize(1);
+  for (int d : s.devices) {
+    fpvhip_ctx* c = AcquireEncoderCtx(d, (uint32_t)xsize, (uint32_t)ysize, s.shift, s.big_endian,
+                                      (uint32_t)s.batch, s.slots_per_dev);
+    if (!c) Fatal("fpvhip_create", fpvhip_last_error(nullptr));
+    s.ctxs.push_back(c);
+    if (fpvhip_set_delta_raw(c, delta_frame)) Fatal("fpvhip_set_delta_raw", fpvhip_last_error(c));
+  }
+  s.slot_busy.assign(s.devices.size(), std::vector<char>(s.slots_per_dev, 0));
+
+  // The delta frame itself: predicted WITHOUT a delta frame (cc:1099-1100),
+  // written as header | u32 size | 0x01 | image core (cc:1092-1103).
+  fpvhip_ctx* c0 = s.ctxs[0];
+  memcpy(fpvhip_stage_in(c0, 0, 0), delta_frame, s.npix * 2);
+  s.CheckHip(fpvhip_predict_submit(c0, 0, 1, 0), c0, "fpvhip_predict_submit");
+  const uint8_t *high, *low, *pv, *flags;
+  s.CheckHip(fpvhip_predict_wait(c0, 0, &high, &low, &pv, &flags), c0, "fpvhip_predict_wait");
+  std::vector<uint8_t> out;
+  out.reserve(s.npix + 64);
+  Append32((uint32_t)xsize, &out);
+  Append32((uint32_t)ysize, &out);
+  Append32(0, &out);
+  out.push_back(1);
+  AppendCore(high, low, flags[0], s.npix, &out);
+  Store32((uint32_t)(out.size() - 8), out.data() + 8);
+  s.bytes_written = out.size();
+  s.initialized = true;
+  if (s.num_threads > 0) s.StartThreads();
+  callback(out.data(), out.size(), payload);
+}
+
+void Encoder::CompressFrame(const uint16_t* img, Callback callback, void* payload) {
+  Impl& s = *impl_;
+  if (!s.initialized || s.finished) Fatal("Encoder::CompressFrame", "Init not called or already finished");
+
+  if (s.num_threads == 0) {  // synchronous path (cc:1136-1141)
+    fpvhip_ctx* c = s.ctxs[0];
+    memcpy(fpvhip_stage_in(c, 0, 0), img, s.npix * 2);
+    s.CheckHip(fpvhip_predict_submit(c, 0, 1, 1), c, "fpvhip_predict_submit");
+    const uint8_t *high, *low, *pv, *flags;
+    s.CheckHip(fpvhip_predict_wait(c, 0, &high, &low, &pv, &flags), c, "fpvhip_predict_wait");
+    std::vector<uint8_t> chunk;
+    BuildFrameChunk(high, low, pv, flags[0], s.npix, s.npv, &chunk);
+    s.offsets.push_back(s.bytes_written);
+    s.bytes_written += chunk.size();
+    s.next_id++;
+    callback(chunk.data(), chunk.size(), payload);
+    return;
+  }
+
+  std::unique_lock<std::mutex> l(s.m);
+  if (!s.cur) s.cur = s.OpenBatchLocked(l);
+  Impl::Batch* b = s.cur;
+  // The copy happens under the lock: only the idle-flush of the dispatcher
+  // contends for it, and it must not submit a batch that is being written.
+  memcpy(fpvhip_stage_in(s.ctxs[b->dev], b->slot, b->n), img, s.npix * 2);
+  b->cbs.push_back(std::move(callback));
+  b->payloads.push_back(payload);
+  b->n++;
+  s.next_id++;
+  s.inflight++;
+  s.cur_touched = std::chrono::steady_clock::now();
+  // Submit when full -- or when we are about to block on the in-flight limit,
+  // because the frames of a partial batch would otherwise never complete.
+  if (b->n == s.batch || s.inflight >= s.max_queued) {
+    s.cur = nullptr;
+    s.SubmitLocked(b);
+  }
+  s.cv_producer.wait(l, [&s] { return s.inflight < s.max_queued; });  // cc:1150-1156
+}
+
+void Encoder::Finish(Callback callback, void* payload) {
+  Impl& s = *impl_;
+  if (s.finished) return;  // cc:1111
+  if (!s.initialized) Fatal("Encoder::Finish", "Init not called");
+  if (s.num_threads > 0) {
+    {
+      std::unique_lock<std::mutex> l(s.m);
+      if (s.cur) {
+        Impl::Batch* b = s.cur;
+        s.cur = nullptr;
+        if (b->n > 0) {
+          s.SubmitLocked(b);
+        } else {
+          s.slot_busy[b->dev][b->slot] = 0;
+          delete b;
+        }
+      }
+      s.cv_producer.wait(l, [&s] { return s.inflight == 0 && s.emit_q.empty(); });
+    }
+    s.StopThreads();
+  }
+  s.finished = true;
+  s.ReleaseContexts();
+  // frame index (cc:1185-1197)
+  const size_t n = s.offsets.size();
+  std::vector<uint8_t> out(5 + 8 * n + 8);
+  Store32((uint32_t)out.size(), out.data());
+  out[4] = 2;
+  for (size_t i = 0; i < n; i++) Store64(s.offsets[i], out.data() + 5 + 8 * i);
+  Store64(n, out.data() + 5 + 8 * n);
+  callback(out.data(), out.size(), payload);
+}
+
+}  // namespace fpvc

@@ -1,0 +1,90 @@
+// fpv_host_internal.h -- helpers shared by the host codec translation units.
+#ifndef FPV_HOST_INTERNAL_H_
+#define FPV_HOST_INTERNAL_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <vector>
+
+#include "fpv_hip.h"
+
+namespace fpvc {
+namespace internal {
+
+bool Failure(const char* file, int line, const char* msg);
+#define FPV_FAILURE(msg) ::fpvc::internal::Failure(__FILE__, __LINE__, msg)
+[[noreturn]] void Fatal(const char* what, const char* detail);
+
+uint32_t Load32(const uint8_t* p);
+uint64_t Load64(const uint8_t* p);
+void Store32(uint32_t v, uint8_t* p);
+void Store64(uint64_t v, uint8_t* p);
+void Append32(uint32_t v, std::vector<uint8_t>* out);
+bool OutOfRange(size_t pos, size_t width, size_t size);
+
+bool BrotliAppend(const uint8_t* in, size_t n, std::vector<uint8_t>* out);
+bool BrotliInto(const uint8_t* in, size_t size, size_t* pos, uint8_t* dst,
+                size_t cap, size_t* got);
+
+std::vector<int> DeviceList();
+size_t EnvSize(const char* name, size_t dflt);
+
+void BuildFrameChunk(const uint8_t* high, const uint8_t* low, const uint8_t* preview,
+                     uint8_t flags, size_t npix, size_t npv, std::vector<uint8_t>* out);
+void AppendCore(const uint8_t* high, const uint8_t* low, uint8_t flags, size_t npix,
+                std::vector<uint8_t>* out);
+
+// Process-wide cache of forward contexts: creating one allocates pinned
+// staging memory (100s of ms), so sessions with the same geometry reuse them.
+fpvhip_ctx* AcquireEncoderCtx(int device, uint32_t xs, uint32_t ys, int shift,
+                              bool big_endian, uint32_t batch, uint32_t slots);
+void ReleaseEncoderCtx(fpvhip_ctx* ctx);
+
+// Inverse predictor front end shared by the two decoders: Brotli-decodes the
+// planes of an image chunk straight into a slot's pinned staging memory and
+// runs the GPU inverse (DecompressImage, cc:296-347).
+class InverseEngine {
+ public:
+  // nullptr (after an stderr line) when no context can be created.
+  static std::shared_ptr<InverseEngine> Create(size_t xs, size_t ys, uint32_t batch,
+                                               uint32_t slots, int device);
+  ~InverseEngine();
+
+  size_t npix() const { return npix_; }
+  uint32_t batch() const { return batch_; }
+  bool SetDelta(const uint16_t* delta16);
+  bool has_delta() const { return has_delta_; }
+
+  // One image: in/size is the image chunk (flags byte, [low stream], high
+  // stream).  On success *frame points at the decoded pixels inside the slot;
+  // the caller must call Release(slot) when done with them.
+  bool Decode(const uint8_t* in, size_t size, const uint16_t** frame, int* slot);
+  void Release(int slot);
+
+  // Many images in GPU batches; outs[i] receives image i.  Brotli decoding of a
+  // batch is spread over `threads` host threads.
+  bool DecodeBatch(const uint8_t* const* ins, const size_t* sizes, size_t n,
+                   uint16_t* const* outs, size_t threads);
+
+ private:
+  InverseEngine() {}
+  int AcquireSlot();
+  bool Unpack(const uint8_t* in, size_t size, uint32_t slot, uint32_t k, uint8_t* flags);
+
+  fpvhip_ctx* ctx_ = nullptr;
+  size_t npix_ = 0;
+  uint32_t batch_ = 1, nslots_ = 1;
+  bool has_delta_ = false;
+  std::mutex m_;
+  std::condition_variable cv_;
+  std::vector<char> busy_;
+};
+
+}  // namespace internal
+}  // namespace fpvc
+
+#endif  // FPV_HOST_INTERNAL_H_

@@ -27,12 +27,15 @@ struct Geom {
   uint32_t stat_blocks;         // workgroups per frame of the stats kernel
   uint32_t ring;                // inverse kernel: LDS ring size (power of two)
   int32_t shift, swap;          // Frame ctor arguments (swap = big_endian on LE host)
+  int32_t fwd_ok;               // forward kernels usable (dims multiples of 4, LDS fits)
 };
 
 // Fills every derived field from xs, ys, shift, big_endian.  Returns false (and
 // a message) when the geometry is not supported by the kernels.
 bool make_geom(uint32_t xs, uint32_t ys, int shift, int big_endian, Geom* g,
                const char** why);
+// Inverse-only geometry: any non-zero dimensions.
+bool make_geom_decoder(uint32_t xs, uint32_t ys, Geom* g, const char** why);
 
 struct FwdWorkspace {
   uint32_t* hists;    // [nframes][kNumHists][256]

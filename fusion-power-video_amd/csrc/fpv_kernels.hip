@@ -357,6 +357,10 @@ __global__ __launch_bounds__(kThreads) void k_preview_finish(
 // residuals in and do delta^-1 + recombine + the coalesced uint16 stores.
 constexpr uint32_t kInvChunk = 1024;  // pixels per staging round (multiple of 256)
 
+// ALIGNED: xs and npix are multiples of 4 (every real frame geometry): dword
+// LDS/global accesses.  Otherwise (odd preview planes, odd-sized files from
+// the CPU reference) a byte-granular path with the same structure.
+template <bool ALIGNED>
 __global__ __launch_bounds__(64) void k_inverse(
     const uint8_t* __restrict__ high, const uint8_t* __restrict__ low,
     const uint8_t* __restrict__ dhigh, const uint8_t* __restrict__ dlow,
@@ -374,16 +378,20 @@ __global__ __launch_bounds__(64) void k_inverse(
   uint32_t w = 0;  // reconstructed value of pixel i-1 (lane 0)
 
   for (uint32_t c0 = 0; c0 < g.npix; c0 += kInvChunk) {
-    const uint32_t cn = min(kInvChunk, g.npix - c0);  // multiple of 16
-    // stage residuals (4 bytes per lane and step, coalesced)
-    for (uint32_t j = lane * 4; j < cn; j += 256)
-      *reinterpret_cast<uint32_t*>(ring + ((c0 + j) & m)) =
-          *reinterpret_cast<const uint32_t*>(hp + c0 + j);
+    const uint32_t cn = min(kInvChunk, g.npix - c0);
+    // stage residuals, coalesced
+    if (ALIGNED) {
+      for (uint32_t j = lane * 4; j < cn; j += 256)
+        *reinterpret_cast<uint32_t*>(ring + ((c0 + j) & m)) =
+            *reinterpret_cast<const uint32_t*>(hp + c0 + j);
+    } else {
+      for (uint32_t j = lane; j < cn; j += 64) ring[(c0 + j) & m] = hp[c0 + j];
+    }
     __syncthreads();
     if (use_cg && lane == 0) {
       uint32_t i = c0;
-      // literals and the unaligned head (cc:327 starts at xs + 1)
-      while (i < c0 + cn && (i < xs + 1 || (i & 3))) {
+      // literals (cc:327 starts at xs + 1) and the unaligned head
+      while (i < c0 + cn && (i < xs + 1 || (i & 3) || !ALIGNED)) {
         uint32_t x = ring[i & m];
         if (i >= xs + 1) {
           x = (x + cg_pred(ring[(i - xs) & m], (int)w, ring[(i - xs - 1) & m])) & 0xffu;
@@ -393,7 +401,7 @@ __global__ __launch_bounds__(64) void k_inverse(
         i++;
       }
       // aligned groups of 4; xs >= 4 keeps a group's north bytes outside itself
-      if (i < c0 + cn) {
+      if (ALIGNED && i < c0 + cn) {
         uint32_t r4 = *reinterpret_cast<uint32_t*>(ring + (i & m));
         uint32_t n4 = *reinterpret_cast<uint32_t*>(ring + ((i - xs) & m));
         uint32_t nw = ring[(i - xs - 1) & m];
@@ -423,20 +431,32 @@ __global__ __launch_bounds__(64) void k_inverse(
       }
     }
     __syncthreads();
-    // delta^-1 + recombine (cc:335-344), 4 pixels per lane and step
-    for (uint32_t j = lane * 4; j < cn; j += 256) {
-      uint32_t h4 = *reinterpret_cast<uint32_t*>(ring + ((c0 + j) & m));
-      uint32_t l4 = no_low ? 0u : *reinterpret_cast<const uint32_t*>(lp + c0 + j);
-      if (use_delta) {
-        h4 = add4(h4, *reinterpret_cast<const uint32_t*>(dhigh + c0 + j));
-        l4 = add4(l4, *reinterpret_cast<const uint32_t*>(dlow + c0 + j));
+    // delta^-1 + recombine (cc:335-344)
+    if (ALIGNED) {
+      for (uint32_t j = lane * 4; j < cn; j += 256) {
+        uint32_t h4 = *reinterpret_cast<uint32_t*>(ring + ((c0 + j) & m));
+        uint32_t l4 = no_low ? 0u : *reinterpret_cast<const uint32_t*>(lp + c0 + j);
+        if (use_delta) {
+          h4 = add4(h4, *reinterpret_cast<const uint32_t*>(dhigh + c0 + j));
+          l4 = add4(l4, *reinterpret_cast<const uint32_t*>(dlow + c0 + j));
+        }
+        uint2 o;
+        o.x = __builtin_amdgcn_perm(h4, l4, 0x05010400u);  // l0 h0 l1 h1
+        o.y = __builtin_amdgcn_perm(h4, l4, 0x07030602u);  // l2 h2 l3 h3
+        *reinterpret_cast<uint2*>(outp + c0 + j) = o;
       }
-      uint2 o;
-      o.x = __builtin_amdgcn_perm(h4, l4, 0x05010400u);  // l0 h0 l1 h1
-      o.y = __builtin_amdgcn_perm(h4, l4, 0x07030602u);  // l2 h2 l3 h3
-      *reinterpret_cast<uint2*>(outp + c0 + j) = o;
+    } else {
+      for (uint32_t j = lane; j < cn; j += 64) {
+        uint32_t h = ring[(c0 + j) & m], l = no_low ? 0u : lp[c0 + j];
+        if (use_delta) {
+          h = (h + dhigh[c0 + j]) & 0xffu;
+          l = (l + dlow[c0 + j]) & 0xffu;
+        }
+        outp[c0 + j] = (uint16_t)((h << 8) | l);
+      }
     }
     // the next round overwrites ring bytes older than xs + 1 + kInvChunk only
+    __syncthreads();
   }
 }
 
@@ -477,6 +497,24 @@ bool make_geom(uint32_t xs, uint32_t ys, int shift, int big_endian, Geom* g,
   uint32_t ring = 1;
   while (ring < xs + 1 + kInvChunk + 4) ring <<= 1;
   g->ring = ring;
+  g->fwd_ok = 1;
+  return true;
+}
+
+bool make_geom_decoder(uint32_t xs, uint32_t ys, Geom* g, const char** why) {
+  static const char* kDims = "xsize and ysize must be non-zero";
+  static const char* kBig = "frame larger than 2^31 pixels";
+  static const char* kWide = "xsize too large for the LDS ring";
+  if (!xs || !ys) { *why = kDims; return false; }
+  if ((uint64_t)xs * ys >= (1ull << 31)) { *why = kBig; return false; }
+  *g = Geom();
+  g->xs = xs; g->ys = ys; g->npix = xs * ys;
+  g->pw = xs / 4; g->ph = ys / 4; g->npv = g->pw * g->ph;
+  uint32_t ring = 1;
+  while (ring < xs + 1 + kInvChunk + 4) ring <<= 1;
+  if (ring > 128 * 1024) { *why = kWide; return false; }
+  g->ring = ring;
+  g->fwd_ok = 0;
   return true;
 }
 
@@ -571,12 +609,18 @@ hipError_t launch_inverse(const Geom& g, const uint8_t* d_high,
                           uint32_t nframes, uint16_t* d_frames, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inverse),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inverse<true>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inverse<false>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
     attr_set = true;
   }
-  k_inverse<<<nframes, 64, g.ring, s>>>(d_high, d_low, d_dhigh, d_dlow, d_flags,
-                                        d_frames, g);
+  if ((g.xs & 3) == 0 && (g.npix & 3) == 0)
+    k_inverse<true><<<nframes, 64, g.ring, s>>>(d_high, d_low, d_dhigh, d_dlow,
+                                                d_flags, d_frames, g);
+  else
+    k_inverse<false><<<nframes, 64, g.ring, s>>>(d_high, d_low, d_dhigh, d_dlow,
+                                                 d_flags, d_frames, g);
   return hipGetLastError();
 }
 

@@ -1,0 +1,56 @@
+/*
+ * fpv_c_api.h -- plain-C entry points over the C++ codec API of
+ * fusion_power_video.h, for FFI callers (the Python tests and bench, or any
+ * language binding).  Exported by libfpv_amd.so.
+ */
+#ifndef FPV_C_API_H_
+#define FPV_C_API_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void (*fpvc_write_fn)(const uint8_t *data, size_t size, void *payload);
+
+/* fpvc::Encoder (h:175-255) */
+void *fpvc_encoder_new(size_t num_threads, int shift, int big_endian);
+size_t fpvc_encoder_max_queued(const void *enc);
+void fpvc_encoder_init(void *enc, const uint16_t *delta, size_t xs, size_t ys,
+                       fpvc_write_fn cb, void *payload);
+void fpvc_encoder_compress_frame(void *enc, const uint16_t *img, fpvc_write_fn cb,
+                                 void *payload);
+void fpvc_encoder_finish(void *enc, fpvc_write_fn cb, void *payload);
+void fpvc_encoder_free(void *enc);
+
+/*
+ * Whole-stream helpers.  encode: Init(delta) + CompressFrame x n + Finish into
+ * out (capacity cap); returns the stream size or 0 when it does not fit.
+ */
+size_t fpvc_encode_stream(const uint16_t *frames, size_t nframes,
+                          const uint16_t *delta_raw, size_t xs, size_t ys,
+                          int shift, int big_endian, size_t num_threads,
+                          uint8_t *out, size_t cap);
+/*
+ * RandomAccessDecoder (h:143-172) over a whole stream: every frame (and, when
+ * previews_out != NULL, every preview).  batched != 0 uses the DecodeFrames
+ * extension.  Returns the frame count or -1.
+ */
+long fpvc_decode_stream(const uint8_t *data, size_t size, uint16_t *frames_out,
+                        size_t cap_frames, uint8_t *previews_out, int batched,
+                        size_t threads);
+/* StreamingDecoder (h:37-57) fed in pieces of `block` bytes. */
+long fpvc_stream_decode(const uint8_t *data, size_t size, size_t block,
+                        uint16_t *frames_out, size_t cap_frames);
+/* Stream header peek: 0 on success. */
+int fpvc_stream_info(const uint8_t *data, size_t size, size_t *xs, size_t *ys,
+                     size_t *nframes);
+void fpvc_unextract(const uint16_t *img, size_t xs, size_t ys, int shift,
+                    int big_endian, uint8_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FPV_C_API_H_ */

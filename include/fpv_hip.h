@@ -11,8 +11,9 @@
  * Conventions
  *   - int results: 0 = ok, < 0 = error (text via fpvhip_last_error).  Nothing
  *     throws.  There is NO CPU fallback: without a usable GPU every call fails.
- *   - One context per (device, frame geometry).  A context is used by one host
- *     thread at a time.  "slot" selects one of the context's independent
+ *   - One context per (device, frame geometry).  Distinct slots of a context
+ *     may be driven from distinct host threads; one slot, and the set_delta_* /
+ *     *_device entry points, by one thread at a time.  "slot" selects one of the context's independent
  *     staging sets (pinned host buffers + device buffers + one HIP stream), so
  *     that slot A can be in flight while the host fills or drains slot B.
  *   - Planes are packed per frame: frame k of a batch starts at k * npix bytes
@@ -52,6 +53,13 @@ const char *fpvhip_last_error(const fpvhip_ctx *ctx);
  */
 fpvhip_ctx *fpvhip_create(int device, uint32_t xs, uint32_t ys, int shift,
                           int big_endian, uint32_t max_batch, uint32_t slots);
+/*
+ * Decoder-only context: any non-zero xs, ys (preview planes are (xs/4)x(ys/4),
+ * files written by the CPU reference may have odd sizes).  Only the
+ * set_delta_decoded / stage_plane / inverse_* entry points work on it.
+ */
+fpvhip_ctx *fpvhip_create_decoder(int device, uint32_t xs, uint32_t ys,
+                                  uint32_t max_batch, uint32_t slots);
 void fpvhip_destroy(fpvhip_ctx *ctx);
 
 /* Geometry helpers. */
@@ -72,6 +80,13 @@ int fpvhip_set_delta_raw(fpvhip_ctx *ctx, const uint16_t *delta_raw);
  * DecompressImage for the delta chunk, cc:903 / cc:984).  Synchronous.
  */
 int fpvhip_set_delta_decoded(fpvhip_ctx *ctx, const uint16_t *delta_img);
+
+/*
+ * Delta frame given as RAW byte planes (Frame API: the delta Frame's high()/
+ * low(), cc:534-537).  low == NULL means an absent low plane (zeros).
+ */
+int fpvhip_set_delta_planes(fpvhip_ctx *ctx, const uint8_t *high,
+                            const uint8_t *low);
 
 /* ---- forward predictor, host-staged (Encoder pipeline) ------------------ */
 

@@ -1,0 +1,194 @@
+/*
+ * fpvhip_oracle_shim.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * A stand-in for libfpvhip.so that implements the host-staged part of the C ABI
+ * (include/fpv_hip.h) with the CPU oracle, so that the HOST logic of the codec
+ * -- container format, batching, worker pool, callback ordering, decoders'
+ * parsing -- can be exercised by `pytest -m "not gpu"` in a container without
+ * a GPU.  It is linked ONLY into tests/shim/libfpv_amd_cpushim.so; the product
+ * libraries never see it and have no CPU path.  The device-resident entry
+ * points fail here.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "fpv_hip.h"
+#include "fpv_oracle.h"
+
+typedef struct {
+  uint16_t *pix;
+  uint8_t *high, *low, *pv, *flags;
+  uint32_t pending;
+} slot_t;
+
+struct fpvhip_ctx {
+  uint32_t xs, ys, batch, nslots;
+  size_t npix, npv;
+  int shift, be, fwd_ok, have_delta;
+  uint8_t *dhigh, *dlow;
+  uint16_t *d16;
+  slot_t *slots;
+  char err[128];
+};
+
+static char g_err[128];
+
+int fpvhip_abi_version(void) { return FPVHIP_ABI_VERSION; }
+int fpvhip_device_count(void) {
+  const char *e = getenv("FPV_SHIM_DEVICES");
+  return e ? atoi(e) : 1;
+}
+const char *fpvhip_last_error(const fpvhip_ctx *c) { return c ? c->err : g_err; }
+
+static fpvhip_ctx *mk(uint32_t xs, uint32_t ys, int shift, int be, uint32_t batch,
+                      uint32_t slots, int fwd) {
+  fpvhip_ctx *c;
+  uint32_t s;
+  if (!xs || !ys || !batch || (fwd && ((xs & 3) || (ys & 3)))) {
+    snprintf(g_err, sizeof g_err, "unsupported geometry %ux%u", xs, ys);
+    return NULL;
+  }
+  c = (fpvhip_ctx *)calloc(1, sizeof *c);
+  c->xs = xs; c->ys = ys; c->batch = batch; c->nslots = slots;
+  c->npix = (size_t)xs * ys; c->npv = (size_t)(xs / 4) * (ys / 4);
+  c->shift = shift; c->be = be; c->fwd_ok = fwd;
+  c->dhigh = (uint8_t *)calloc(c->npix, 1);
+  c->dlow = (uint8_t *)calloc(c->npix, 1);
+  c->d16 = (uint16_t *)calloc(c->npix, 2);
+  c->slots = (slot_t *)calloc(slots ? slots : 1, sizeof(slot_t));
+  for (s = 0; s < slots; s++) {
+    c->slots[s].pix = (uint16_t *)calloc(c->npix * batch, 2);
+    c->slots[s].high = (uint8_t *)calloc(c->npix * batch, 1);
+    c->slots[s].low = (uint8_t *)calloc(c->npix * batch, 1);
+    c->slots[s].pv = (uint8_t *)calloc((c->npix / 16 + c->npv + 16) * batch, 1);
+    c->slots[s].flags = (uint8_t *)calloc(batch, 1);
+  }
+  return c;
+}
+
+fpvhip_ctx *fpvhip_create(int device, uint32_t xs, uint32_t ys, int shift, int be,
+                          uint32_t batch, uint32_t slots) {
+  (void)device;
+  return mk(xs, ys, shift, be, batch, slots, 1);
+}
+fpvhip_ctx *fpvhip_create_decoder(int device, uint32_t xs, uint32_t ys, uint32_t batch,
+                                  uint32_t slots) {
+  (void)device;
+  return mk(xs, ys, 0, 0, batch, slots, 0);
+}
+void fpvhip_destroy(fpvhip_ctx *c) {
+  uint32_t s;
+  if (!c) return;
+  for (s = 0; s < c->nslots; s++) {
+    free(c->slots[s].pix); free(c->slots[s].high); free(c->slots[s].low);
+    free(c->slots[s].pv); free(c->slots[s].flags);
+  }
+  free(c->slots); free(c->dhigh); free(c->dlow); free(c->d16); free(c);
+}
+size_t fpvhip_npix(const fpvhip_ctx *c) { return c->npix; }
+size_t fpvhip_npreview(const fpvhip_ctx *c) { return c->npv; }
+uint32_t fpvhip_max_batch(const fpvhip_ctx *c) { return c->batch; }
+uint32_t fpvhip_slots(const fpvhip_ctx *c) { return c->nslots; }
+
+int fpvhip_set_delta_raw(fpvhip_ctx *c, const uint16_t *d) {
+  fpvo_split(d, c->npix, c->shift, c->be, c->dhigh, c->dlow);
+  if (c->shift == 8) memset(c->dlow, 0, c->npix);
+  c->have_delta = 1;
+  return 0;
+}
+int fpvhip_set_delta_decoded(fpvhip_ctx *c, const uint16_t *d) {
+  memcpy(c->d16, d, c->npix * 2);
+  c->have_delta = 1;
+  return 0;
+}
+int fpvhip_set_delta_planes(fpvhip_ctx *c, const uint8_t *h, const uint8_t *l) {
+  memcpy(c->dhigh, h, c->npix);
+  if (l) memcpy(c->dlow, l, c->npix); else memset(c->dlow, 0, c->npix);
+  c->have_delta = 1;
+  return 0;
+}
+
+uint16_t *fpvhip_stage_in(fpvhip_ctx *c, uint32_t slot, uint32_t k) {
+  return c->slots[slot].pix + (size_t)k * c->npix;
+}
+int fpvhip_predict_submit(fpvhip_ctx *c, uint32_t slot, uint32_t n, int with_delta) {
+  slot_t *s = &c->slots[slot];
+  uint32_t k;
+  uint8_t *pv = (uint8_t *)malloc(c->npix / 16 + c->npv + 16);
+  if (!c->fwd_ok || (with_delta && !c->have_delta)) {
+    snprintf(c->err, sizeof c->err, "bad predict_submit");
+    free(pv);
+    return -1;
+  }
+  for (k = 0; k < n; k++) {
+    s->flags[k] = fpvo_predict(s->pix + (size_t)k * c->npix, c->xs, c->ys, c->shift, c->be,
+                               with_delta ? c->dhigh : NULL, with_delta ? c->dlow : NULL,
+                               s->high + (size_t)k * c->npix, s->low + (size_t)k * c->npix, pv);
+    memcpy(s->pv + (size_t)k * c->npv, pv, c->npv);
+  }
+  free(pv);
+  s->pending = n;
+  return 0;
+}
+int fpvhip_predict_wait(fpvhip_ctx *c, uint32_t slot, const uint8_t **high,
+                        const uint8_t **low, const uint8_t **pv, const uint8_t **flags) {
+  slot_t *s = &c->slots[slot];
+  if (!s->pending) { snprintf(c->err, sizeof c->err, "nothing in flight"); return -1; }
+  s->pending = 0;
+  if (high) *high = s->high;
+  if (low) *low = s->low;
+  if (pv) *pv = s->pv;
+  if (flags) *flags = s->flags;
+  return 0;
+}
+
+uint8_t *fpvhip_stage_plane(fpvhip_ctx *c, uint32_t slot, uint32_t k, int which) {
+  slot_t *s = &c->slots[slot];
+  return (which ? s->low : s->high) + (size_t)k * c->npix;
+}
+int fpvhip_inverse_submit(fpvhip_ctx *c, uint32_t slot, uint32_t n, const uint8_t *flags) {
+  slot_t *s = &c->slots[slot];
+  uint32_t k;
+  for (k = 0; k < n; k++) {
+    if ((flags[k] & 1) && !c->have_delta) {
+      snprintf(c->err, sizeof c->err, "delta frame not given");
+      return -1;
+    }
+    fpvo_inverse(s->high + (size_t)k * c->npix,
+                 (flags[k] & 4) ? NULL : s->low + (size_t)k * c->npix,
+                 c->have_delta ? c->d16 : NULL, c->xs, c->ys, flags[k],
+                 s->pix + (size_t)k * c->npix);
+  }
+  s->pending = n;
+  return 0;
+}
+int fpvhip_inverse_wait(fpvhip_ctx *c, uint32_t slot, const uint16_t **frames) {
+  slot_t *s = &c->slots[slot];
+  if (!s->pending) { snprintf(c->err, sizeof c->err, "nothing in flight"); return -1; }
+  s->pending = 0;
+  if (frames) *frames = s->pix;
+  return 0;
+}
+
+#define NOPE(c) (snprintf((c)->err, sizeof (c)->err, "device entry points need the GPU library"), -1)
+int fpvhip_predict_device(fpvhip_ctx *c, const void *a, uint32_t n, int wd, void *h, void *l,
+                          void *p, void *f, void *s) {
+  (void)a; (void)n; (void)wd; (void)h; (void)l; (void)p; (void)f; (void)s;
+  return NOPE(c);
+}
+int fpvhip_inverse_device(fpvhip_ctx *c, const void *h, const void *l, const void *f, uint32_t n,
+                          void *o, void *s) {
+  (void)h; (void)l; (void)f; (void)n; (void)o; (void)s;
+  return NOPE(c);
+}
+double fpvhip_time_predict_device(fpvhip_ctx *c, const void *a, uint32_t n, int wd, void *h,
+                                  void *l, void *p, void *f, void *s, int it, double *km) {
+  (void)a; (void)n; (void)wd; (void)h; (void)l; (void)p; (void)f; (void)s; (void)it; (void)km;
+  return NOPE(c);
+}
+double fpvhip_time_inverse_device(fpvhip_ctx *c, const void *h, const void *l, const void *f,
+                                  uint32_t n, void *o, void *s, int it) {
+  (void)h; (void)l; (void)f; (void)n; (void)o; (void)s; (void)it;
+  return NOPE(c);
+}

@@ -1,0 +1,118 @@
+"""Host codec logic (container format, batching, worker pool, callback order,
+decoder parsing) WITHOUT a GPU: the same host sources linked against the
+oracle-backed stand-in for the C ABI (tests/shim).  Compared with golden
+streams produced by the real reference."""
+import hashlib
+import importlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SHIM = os.path.join(HERE, "shim", "libfpv_amd_cpushim.so")
+GOLD = np.load(os.path.join(HERE, "golden", "edge_cases.npz"))
+MAN = json.load(open(os.path.join(HERE, "golden", "manifest.json")))
+NAMES = [str(n) for n in GOLD["names"]]
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def codec(fpv):
+    if not os.path.exists(SHIM):
+        pytest.skip("tests/shim/libfpv_amd_cpushim.so not built (make shim)")
+    return importlib.import_module("fpv_amd.codec").Codec(SHIM)
+
+
+@pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("threads", [0, 3])
+def test_edge_streams_match_reference(codec, name, threads):
+    frames, delta = GOLD[name + "/frames"], GOLD[name + "/delta"]
+    xs, ys, shift, be = (int(v) for v in GOLD[name + "/meta"])
+    fpv = codec.encode_stream(frames, delta, xs, ys, shift, bool(be), threads=threads)
+    assert np.array_equal(fpv, GOLD[name + "/fpv"])
+    dec, pv = codec.decode_stream(fpv, with_previews=True)
+    assert np.array_equal(dec, GOLD[name + "/decoded"])
+    assert np.array_equal(pv, GOLD[name + "/decoded_preview"])
+    assert np.array_equal(codec.decode_stream(fpv, batched=True, threads=2), GOLD[name + "/decoded"])
+    for block in (1, 13, 4096, 1 << 20):
+        assert np.array_equal(codec.stream_decode(fpv, xs, ys, frames.shape[0], block=block),
+                              GOLD[name + "/decoded"])
+
+
+@pytest.mark.parametrize("threads", [0, 1, 4, 16])
+def test_noise_config0_stream(codec, synth, threads):
+    w = MAN["workloads"]["noise_256x256x64_seed1"]
+    nz = synth.noise_frames(64, 256, 256, seed=1)
+    fpv = codec.encode_stream(nz, nz[0], 256, 256, 0, False, threads=threads)
+    assert fpv.size == w["fpv_size"] and sha(fpv) == w["fpv_sha256"]
+
+
+def test_plasma_stream_and_decoders(codec, synth):
+    w = MAN["workloads"]["plasma12_1280x800x20_seed7"]
+    pl = synth.plasma_frames(20, 1280, 800, bits=12, seed=7)
+    fpv = codec.encode_stream(pl, pl[0], 1280, 800, 4, False, threads=8)
+    assert sha(fpv) == w["fpv_sha256"]
+    assert np.array_equal(codec.decode_stream(fpv, batched=True, threads=4), pl << 4)
+    assert np.array_equal(codec.stream_decode(fpv, 1280, 800, 20, block=1 << 20), pl << 4)
+    raw = codec.unextract(codec.decode_stream(fpv)[7], 1280, 800, 4, False)
+    assert np.array_equal(raw.view(np.uint16), pl[7].reshape(-1))
+
+
+def test_callbacks_in_order_with_payloads(codec, synth):
+    fr = synth.noise_frames(50, 64, 48, seed=2)
+    for threads in (0, 2, 9):
+        mq, got = codec.encode_with_callbacks(fr, fr[0], 64, 48, threads=threads)
+        assert mq == (1 if threads == 0 else mq) and mq >= max(1, threads)
+        assert [g[0] for g in got] == [1000000] + list(range(1, 51)) + [2000000]   # Finish twice = once
+        stream = np.frombuffer(b"".join(g[1] for g in got), np.uint8)
+        assert np.array_equal(codec.decode_stream(stream), fr)
+        # frame index offsets point at the chunks in emission order
+        n = 50
+        foot = stream[-(5 + 8 * n + 8):]
+        offs = np.frombuffer(foot[5:5 + 8 * n].tobytes(), "<u8")
+        pos = len(got[0][1])
+        for k in range(n):
+            assert offs[k] == pos
+            pos += len(got[1 + k][1])
+
+
+def test_zero_frames_stream(codec, synth):
+    fr = synth.noise_frames(1, 64, 48, seed=4)
+    fpv = codec.encode_stream(fr[:0], fr[0], 64, 48, threads=2)
+    assert codec.stream_info(fpv) == (64, 48, 0)
+    assert codec.decode_stream(fpv).shape[0] == 0
+
+
+def test_corrupt_streams_fail_cleanly(codec, capfd):
+    name = "plasma12_le_s4"
+    good = GOLD[name + "/fpv"].copy()
+    bad = good.copy()
+    bad[12] = 0                                     # delta chunk flag must be 1
+    with pytest.raises(RuntimeError):
+        codec.decode_stream(bad)
+    assert "failure at:" in capfd.readouterr().err  # same diagnostics style as the reference
+    bad = good.copy()
+    bad[-9] ^= 0xFF                                 # last frame offset in the index
+    with pytest.raises(RuntimeError):
+        codec.decode_stream(bad)
+    bad = good.copy()
+    bad[40:60] ^= 0x55                              # inside the delta frame's Brotli data
+    with pytest.raises(RuntimeError):
+        codec.decode_stream(bad)
+    with pytest.raises(RuntimeError):
+        codec.stream_decode(bad, 64, 48, 3, block=100)
+    with pytest.raises(RuntimeError):
+        codec.decode_stream(good[:-4])              # truncated footer
+    # a truncated stream simply yields fewer frames from the streaming decoder
+    assert codec.stream_decode(good[:good.size // 2], 64, 48, 3, block=777).shape[0] < 3
+
+
+def test_unextract_matches_oracle(codec, oracle, synth):
+    img = synth.noise_frames(1, 64, 48, seed=8)[0]
+    for shift, be in ((0, False), (4, False), (4, True), (8, True)):
+        assert np.array_equal(codec.unextract(img, 64, 48, shift, be), oracle.unextract(img, shift, be))

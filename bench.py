@@ -109,7 +109,7 @@ def main():
 
     # HIP-event timing on the launch stream: whole pipeline and per kernel
     ev_ms, kernel_ms = pred.time_predict(d_frames, out, max(args.steps, 5), per_kernel=True)
-    names = ["k_stats", "k_decide", "k_apply", "k_preview_finish"]
+    names = ["k_fused", "k_decide_spec", "redo_lists(3 launches)", "k_finish"]
     dom = int(np.argmax(kernel_ms))
     dom_s = kernel_ms[dom] / 1e3
     achieved = n * ALG_BYTES_PER_FRAME / dom_s / 1e9

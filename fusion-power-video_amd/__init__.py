@@ -63,6 +63,8 @@ def _declare_hip(lib):
     lib.fpvhip_time_predict_device.restype = c.c_double
     lib.fpvhip_time_predict_device.argtypes = [vp, vp, u32, i32, vp, vp, vp, vp, vp, i32,
                                                c.POINTER(c.c_double)]
+    lib.fpvhip_time_copy_device.restype = c.c_double
+    lib.fpvhip_time_copy_device.argtypes = [vp, vp, c.c_size_t, vp, i32]
     lib.fpvhip_time_inverse_device.restype = c.c_double
     lib.fpvhip_time_inverse_device.argtypes = [vp, vp, vp, vp, u32, vp, vp, i32]
     for name in ("fpvhip_set_delta_raw", "fpvhip_set_delta_decoded", "fpvhip_predict_submit",
@@ -103,6 +105,18 @@ def _err(ctx=None):
 
 def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def copy_bandwidth_GBps(nbytes=1 << 30, iters=10, device=0):
+    """Measured device-copy rate (read + write bytes per second) on this GPU."""
+    lib = hip_lib()
+    src = torch.empty(nbytes, dtype=torch.uint8, device=f"cuda:{device}").random_(0, 255)
+    dst = torch.empty_like(src)
+    ms = lib.fpvhip_time_copy_device(_ptr(dst), _ptr(src), nbytes,
+                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), iters)
+    if ms <= 0:
+        raise FpvError("copy timing failed")
+    return 2.0 * nbytes * iters / (ms / 1e3) / 1e9
 
 
 class Predictor:

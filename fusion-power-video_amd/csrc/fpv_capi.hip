@@ -96,6 +96,7 @@ int alloc_slot(fpvhip_ctx* c, Slot* s) {
   if (c->g.fwd_ok) {
     HIPOK(c, hipMalloc(&s->d_ws, fpvhip::fwd_workspace_bytes(c->g, c->max_batch)));
     fpvhip::carve_fwd_workspace(c->g, c->max_batch, s->d_ws, &s->ws);
+    HIPOK(c, fpvhip::init_fwd_workspace(s->ws, s->stream));
   }
   return 0;
 }
@@ -165,6 +166,8 @@ static fpvhip_ctx* create_impl(int device, const Geom& g, uint32_t max_batch,
     if (g.fwd_ok) {
       HIPOK(c, hipMalloc(&c->d_ws, fpvhip::fwd_workspace_bytes(g, max_batch)));
       fpvhip::carve_fwd_workspace(g, max_batch, c->d_ws, &c->ws);
+      HIPOK(c, fpvhip::init_fwd_workspace(c->ws, nullptr));
+      HIPOK(c, hipStreamSynchronize(nullptr));
     }
     for (auto& e : c->ev) HIPOK(c, hipEventCreate(&e));
     c->slots.resize(slots);
@@ -405,6 +408,22 @@ double fpvhip_time_predict_device(fpvhip_ctx* c, const void* d_frames,
       }
     }
   }
+  return ms;
+}
+
+double fpvhip_time_copy_device(void* d_dst, const void* d_src, size_t bytes, void* stream,
+                               int iters) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipEvent_t a, b;
+  if (iters <= 0 || hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1.0;
+  fpvhip::launch_copy(d_src, d_dst, bytes, st);  // warm
+  hipEventRecord(a, st);
+  for (int i = 0; i < iters; i++) fpvhip::launch_copy(d_src, d_dst, bytes, st);
+  hipEventRecord(b, st);
+  float ms = -1.f;
+  if (hipEventSynchronize(b) == hipSuccess) hipEventElapsedTime(&ms, a, b);
+  hipEventDestroy(a);
+  hipEventDestroy(b);
   return ms;
 }
 

@@ -22,11 +22,20 @@ struct Geom {
   uint32_t tiles;               // tiles per frame
   uint32_t lds_off;             // byte offset of tile pixel 0 inside the line buffer
   uint32_t lds_h_bytes;         // bytes of the high line buffer (16-aligned)
+  uint32_t lds_hist_off;        // byte offset of the 3 LDS histograms
   uint32_t lds_bytes;           // total dynamic LDS of the forward kernel
+  uint32_t group;               // frames per workgroup of the fused kernel
+  uint32_t stream;              // use the barrier-free streaming kernel
+  uint32_t strip_rows, strips;  // streaming kernel: rows per wave strip, strips per frame
+  uint32_t ring_fwd, ring_base; // streaming kernel: LDS ring size (pow2), offset of strip pixel 0
+  uint32_t nacc;                // streaming kernel: preview accumulator rows
+  uint32_t wave_lds;            // streaming kernel: LDS bytes per wave
+  uint32_t stream_waves_per_cu; // streaming kernel: persistent waves per CU
   uint32_t nd, ncg;             // sample counts of the two heuristics
   uint32_t stat_blocks;         // workgroups per frame of the stats kernel
   uint32_t ring;                // inverse kernel: LDS ring size (power of two)
   int32_t shift, swap;          // Frame ctor arguments (swap = big_endian on LE host)
+  int32_t xcd_map;              // forward kernel: XCD-partitioned tile ranges (speed only)
   int32_t fwd_ok;               // forward kernels usable (dims multiples of 4, LDS fits)
 };
 
@@ -38,14 +47,24 @@ bool make_geom(uint32_t xs, uint32_t ys, int shift, int big_endian, Geom* g,
 bool make_geom_decoder(uint32_t xs, uint32_t ys, Geom* g, const char** why);
 
 struct FwdWorkspace {
-  uint32_t* hists;    // [nframes][kNumHists][256]
-  uint32_t* anylow;   // [nframes]  OR of raw low bytes
-  uint8_t* decision;  // [nframes]  bit0 delta, bit1 CG
-  uint8_t* pv_raw;    // [nframes][npv] un-predicted preview
+  uint32_t* hists;     // [nframes][kNumHists][256] exact histograms of redone frames
+  uint32_t* anylow;    // [nframes]  OR of raw low bytes
+  uint32_t* counters;  // |list A|, |list B|, votes[4]
+  uint8_t* decision;   // [nframes]  bit0 delta, bit1 CG
+  uint32_t* list_a;    // frames whose delta decision was mis-speculated
+  uint32_t* list_b;    // frames to re-apply under their true flags
+  uint8_t* pv_raw;     // [nframes][npv] un-predicted preview
+  uint16_t* partials;  // [nframes][tiles][3][256] per-tile histograms of the fused pass
+  uint8_t* spec;       // speculated flags for the next batch
+  size_t zero_fixed;   // bytes in front of hists that every batch zeroes (counters, anylow)
 };
 size_t fwd_workspace_bytes(const Geom& g, uint32_t nframes);
 void carve_fwd_workspace(const Geom& g, uint32_t nframes, void* base,
                          FwdWorkspace* ws);
+hipError_t init_fwd_workspace(const FwdWorkspace& ws, hipStream_t s);
+
+// Plain device copy (bench: measured HBM ceiling).
+hipError_t launch_copy(const void* src, void* dst, size_t bytes, hipStream_t s);
 
 // Raw split of one frame into byte planes (delta frame set-up, cc:370-451).
 hipError_t launch_split(const Geom& g, const uint16_t* d_img, uint8_t* d_high,
@@ -55,7 +74,7 @@ hipError_t launch_split_decoded(const Geom& g, const uint16_t* d_img,
                                 uint8_t* d_high, uint8_t* d_low, hipStream_t s);
 
 // Forward predictor for nframes frames.  ev, when non-null, points to 5 events
-// recorded before/after each launch (timing pass).
+// recorded around [fused, decide, redo x3, finish] (timing pass).
 hipError_t launch_predict(const Geom& g, const uint16_t* d_frames,
                           uint32_t nframes, const uint8_t* d_dhigh,
                           const uint8_t* d_dlow, const FwdWorkspace& ws,

@@ -16,6 +16,10 @@
 // pixel.  The first xs+1 bytes of a predicted plane are literals (cc:572).
 #include "fpv_kernels.h"
 
+#include <stdlib.h>
+
+#include <algorithm>
+
 namespace fpvhip {
 
 namespace {
@@ -92,6 +96,15 @@ __device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t* scratch) {
   return scratch[0] + scratch[1] + scratch[2] + scratch[3];
 }
 
+// Streaming copy, 16 B per lane: the measured HBM ceiling the predictor kernels
+// are compared with (bench only).
+__global__ __launch_bounds__(kThreads) void k_copy(const uint4* __restrict__ src,
+                                                  uint4* __restrict__ dst, size_t n16) {
+  const size_t stride = (size_t)gridDim.x * kThreads;
+  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n16; i += stride)
+    dst[i] = src[i];
+}
+
 // ------------------------------------------------------------- raw split ---
 
 template <bool SWAP>
@@ -120,59 +133,680 @@ __global__ __launch_bounds__(kThreads) void k_split_decoded(
   *reinterpret_cast<uint32_t*>(low + i) = l4;
 }
 
-// ------------------------------------------------------- heuristic stats ---
+// ------------------------------------------------------- forward predictor --
+//
+// The two predictor decisions of a frame depend on histograms of sampled
+// pixels (cc:526-533, cc:553-564), i.e. the reference makes a pass over the
+// frame before it transforms it.  A second read of every frame would cost a
+// third of the HBM traffic, so the forward path SPECULATES:
+//
+//   k_fused        one pass per frame: split, preview, delta and CG residuals
+//                  under the speculated flags, AND the exact histograms of the
+//                  heuristics for that speculation, written as per-tile partials
+//   k_decide_spec  reduces the partials, evaluates EstimateEntropy, compares
+//                  the true decision with the speculation; mis-speculated
+//                  frames go to list A (delta decision wrong: histograms of the
+//                  CG decision are void) or list B (only the CG decision wrong)
+//   k_stats_list / k_decide_list / k_apply_list
+//                  exact, non-speculative redo of the listed frames (normally
+//                  none: these launches exit at once)
+//   k_finish       preview clamped gradient, flags byte, next speculation
+//
+// The speculation only ever changes speed: every frame's output is produced
+// under its TRUE flags.
 
-// One thread per sample.  Histograms are exact (integer atomics; order does
-// not matter).
+constexpr int kMaxIter = 5;        // 16-pixel segments per thread and tile held in registers
+constexpr int kHistFused = 3;      // partial histograms per tile: d, a, b
+constexpr int kListGrid = 1024;    // workgroups of the list-driven kernels
+
+// Tile geometry shared by the tile routines.
+struct TileCtx {
+  uint32_t s, npx, nseg, rows, row0;
+};
+
+__device__ __forceinline__ TileCtx tile_ctx(const Geom& g, uint32_t tile) {
+  TileCtx t;
+  t.row0 = tile * g.tile_rows;
+  t.rows = min(g.tile_rows, g.ys - t.row0);
+  t.s = t.row0 * g.xs;
+  t.npx = t.rows * g.xs;
+  t.nseg = t.npx >> 4;
+  return t;
+}
+
+// Dynamic LDS layout of the tile routines:
+//   [0, lds_h_bytes)            high line buffer: halo (xs+16 bytes in front of
+//                               lds_off) + the tile's post-delta high bytes
+//   [lds_h_bytes, +tile_px/2)   4-pixel sums of the raw high bytes (u16)
+//   then 3 x 256 u32            histograms (fused kernel)
+//   last 16 bytes               OR of the raw low bytes
+struct TileLds {
+  uint8_t* hbuf;
+  uint16_t* psum;
+  uint32_t* hist;
+  uint32_t* s_or;
+};
+
+__device__ __forceinline__ TileLds tile_lds(uint8_t* smem, const Geom& g) {
+  TileLds l;
+  l.hbuf = smem;
+  l.psum = reinterpret_cast<uint16_t*>(smem + g.lds_h_bytes);
+  l.hist = reinterpret_cast<uint32_t*>(smem + g.lds_hist_off);
+  l.s_or = reinterpret_cast<uint32_t*>(smem + g.lds_bytes - 16);
+  return l;
+}
+
+// Halo: post-delta high bytes of the xs+16 pixels in front of the tile, 4 per
+// thread and step.  dcache: this thread's cached delta-high dwords (or null).
 template <bool SWAP>
-__global__ __launch_bounds__(kThreads) void k_stats(
-    const uint16_t* __restrict__ frames, const uint8_t* __restrict__ dhigh,
-    uint32_t* __restrict__ hists, Geom g, int with_delta) {
-  __shared__ uint32_t lh[kNumHists * 256];
-  const uint32_t frame = blockIdx.y;
-  const uint16_t* img = frames + (size_t)frame * g.npix;
-  for (int b = threadIdx.x; b < kNumHists * 256; b += kThreads) lh[b] = 0;
-  __syncthreads();
+__device__ __forceinline__ void load_halo(const Geom& g, const TileCtx& t, const TileLds& L,
+                                          const uint16_t* img, const uint8_t* dhigh,
+                                          bool use_delta) {
+  const uint32_t hs = t.s - g.xs - 16, ngrp = (g.xs + 16) >> 2;
+  for (uint32_t k = threadIdx.x; k < ngrp; k += kThreads) {
+    const uint2 v = *reinterpret_cast<const uint2*>(img + hs + 4 * k);
+    uint32_t h4, l4;
+    split4<SWAP>(v.x, v.y, g.shift, &h4, &l4);
+    if (use_delta) h4 = sub4(h4, *reinterpret_cast<const uint32_t*>(dhigh + hs + 4 * k));
+    *reinterpret_cast<uint32_t*>(L.hbuf + g.lds_off - (g.xs + 16) + 4 * k) = h4;
+  }
+}
 
-  const uint32_t stride = gridDim.x * kThreads;
-  const uint32_t t0 = blockIdx.x * kThreads + threadIdx.x;
-  uint32_t h, l;
-  if (with_delta) {  // cc:526-531: counta of high[0::15]
-    for (uint32_t k = t0; k < g.nd; k += stride) {
-      split1<SWAP>(img[15u * k], g.shift, &h, &l);
-      atomicAdd(&lh[h], 1u);
+// Phase A for one 16-pixel segment: split, preview sums, NO_LOW OR, optional
+// histogram sample of the raw high byte (i % 15 == 0), delta, low plane store,
+// high bytes into LDS (and to global when CG is off).
+template <bool SWAP, bool STATS>
+__device__ __forceinline__ void seg_phase_a(const Geom& g, const TileCtx& t, const TileLds& L,
+                                            uint32_t o, const uint4& pa, const uint4& pb,
+                                            const uint4& dh, const uint4& dl, bool use_delta,
+                                            bool use_cg, uint8_t* high_f, uint8_t* low_f,
+                                            uint32_t* or_low) {
+  const int S = g.shift;
+  uint4 h, l;
+  split4<SWAP>(pa.x, pa.y, S, &h.x, &l.x);
+  split4<SWAP>(pa.z, pa.w, S, &h.y, &l.y);
+  split4<SWAP>(pb.x, pb.y, S, &h.z, &l.z);
+  split4<SWAP>(pb.z, pb.w, S, &h.w, &l.w);
+  uint2 ps;  // cc:500-509: sums of 4 consecutive RAW high bytes
+  ps.x = __builtin_amdgcn_sad_u8(h.x, 0, 0) | (__builtin_amdgcn_sad_u8(h.y, 0, 0) << 16);
+  ps.y = __builtin_amdgcn_sad_u8(h.z, 0, 0) | (__builtin_amdgcn_sad_u8(h.w, 0, 0) << 16);
+  *reinterpret_cast<uint2*>(L.psum + (o >> 2)) = ps;
+  if (S != 8) *or_low |= l.x | l.y | l.z | l.w;  // RAW low bytes (cc:396, 414, 426, 442)
+  if (STATS) {  // cc:526-531: counta of high[0::15]
+    const uint32_t m = (t.s + o) % 15u;
+    const uint32_t j0 = m ? 15u - m : 0u;  // 0..14: first sampled pixel of the segment
+    const uint32_t d = j0 >> 2;
+    uint32_t v = d == 0 ? h.x : d == 1 ? h.y : d == 2 ? h.z : h.w;
+    atomicAdd(&L.hist[(v >> (8 * (j0 & 3))) & 0xffu], 1u);
+    if (j0 == 0) atomicAdd(&L.hist[h.w >> 24], 1u);  // pixel 15 of the segment
+  }
+  if (use_delta) {  // cc:534-537
+    h.x = sub4(h.x, dh.x); h.y = sub4(h.y, dh.y);
+    h.z = sub4(h.z, dh.z); h.w = sub4(h.w, dh.w);
+    if (S != 8) {
+      l.x = sub4(l.x, dl.x); l.y = sub4(l.y, dl.y);
+      l.z = sub4(l.z, dl.z); l.w = sub4(l.w, dl.w);
     }
   }
-  for (uint32_t k = t0; k < g.ncg; k += stride) {  // cc:554-562
-    const uint32_t i = g.xs + 1 + 31u * k;
-    uint32_t x, n, w, nw;
-    split1<SWAP>(img[i], g.shift, &x, &l);
-    split1<SWAP>(img[i - g.xs], g.shift, &n, &l);
-    split1<SWAP>(img[i - 1], g.shift, &w, &l);
-    split1<SWAP>(img[i - g.xs - 1], g.shift, &nw, &l);
-    atomicAdd(&lh[1 * 256 + x], 1u);
-    atomicAdd(&lh[2 * 256 + ((x - cg_pred(n, w, nw)) & 0xffu)], 1u);
-    if (with_delta) {
-      x = (x - dhigh[i]) & 0xffu;
-      n = (n - dhigh[i - g.xs]) & 0xffu;
-      w = (w - dhigh[i - 1]) & 0xffu;
-      nw = (nw - dhigh[i - g.xs - 1]) & 0xffu;
-      atomicAdd(&lh[3 * 256 + x], 1u);
-      atomicAdd(&lh[4 * 256 + ((x - cg_pred(n, w, nw)) & 0xffu)], 1u);
+  if (S != 8) *reinterpret_cast<uint4*>(low_f + t.s + o) = l;
+  *reinterpret_cast<uint4*>(L.hbuf + g.lds_off + o) = h;
+  if (!use_cg) *reinterpret_cast<uint4*>(high_f + t.s + o) = h;
+}
+
+// Phase B for one segment: clamped-gradient residuals (cc:566-572) from the LDS
+// line buffer and, with STATS, the CG heuristic's sample (cc:554-562).
+template <bool STATS>
+__device__ __forceinline__ void seg_phase_b(const Geom& g, const TileCtx& t, const TileLds& L,
+                                            uint32_t o, bool use_cg, uint8_t* high_f) {
+  const uint8_t* cp = L.hbuf + g.lds_off + o;
+  if (use_cg) {
+    const uint8_t* np = cp - g.xs;
+    uint32_t c[5], n[5];
+    c[0] = *reinterpret_cast<const uint32_t*>(cp - 4);
+    const uint4 cv = *reinterpret_cast<const uint4*>(cp);
+    c[1] = cv.x; c[2] = cv.y; c[3] = cv.z; c[4] = cv.w;
+#pragma unroll
+    for (int k = 0; k < 5; k++) n[k] = *reinterpret_cast<const uint32_t*>(np - 4 + 4 * k);
+    uint32_t out[4];
+    int wprev = (int)byte_of(c[0], 3), nwprev = (int)byte_of(n[0], 3);
+    const bool lit = t.s + o < g.xs + 1;  // segment reaches into the literal prefix (cc:572)
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      uint32_t r = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int x = (int)byte_of(c[k + 1], j), nn = (int)byte_of(n[k + 1], j);
+        int res = (x - cg_pred(nn, wprev, nwprev)) & 0xff;
+        if (lit && t.s + o + 4 * k + j < g.xs + 1) res = x;
+        r |= (uint32_t)res << (8 * j);
+        wprev = x;
+        nwprev = nn;
+      }
+      out[k] = r;
+    }
+    *reinterpret_cast<uint4*>(high_f + t.s + o) = make_uint4(out[0], out[1], out[2], out[3]);
+  }
+  if (STATS) {  // samples at i = xs + 1 + 31 k
+    const int q = (int)(t.s + o) - (int)(g.xs + 1);
+    uint32_t j1;
+    if (q >= 0) {
+      const uint32_t r = (uint32_t)q % 31u;
+      j1 = r ? 31u - r : 0u;
+    } else {
+      j1 = (uint32_t)(-q);
+    }
+    if (j1 < 16) {
+      const uint8_t* p = cp + j1;
+      const int x = p[0], w = p[-1], n = p[-(int)g.xs], nw = p[-(int)g.xs - 1];
+      atomicAdd(&L.hist[256 + x], 1u);
+      atomicAdd(&L.hist[512 + ((x - cg_pred(n, w, nw)) & 0xff)], 1u);
     }
   }
-  __syncthreads();
-  uint32_t* gh = hists + (size_t)frame * kNumHists * 256;
-  for (int b = threadIdx.x; b < kNumHists * 256; b += kThreads) {
-    uint32_t v = lh[b];
-    if (v) atomicAdd(&gh[b], v);
+}
+
+// 4x4 preview boxes of the tile from the 4-pixel sums (cc:500-512).
+__device__ __forceinline__ void tile_preview(const Geom& g, const TileCtx& t, const TileLds& L,
+                                             uint8_t* pv_f) {
+  const uint32_t xq = g.xs >> 2;  // psum entries per image row
+  uint8_t* pvo = pv_f + (size_t)(t.row0 >> 2) * g.pw;
+  if ((g.pw & 3) == 0) {  // 4 preview pixels per thread: 8-byte LDS reads, one dword store
+    const uint32_t pw4 = g.pw >> 2, ngrp = (t.rows >> 2) * pw4;
+    for (uint32_t q = threadIdx.x; q < ngrp; q += kThreads) {
+      const uint32_t pr = q / pw4, pc = (q - pr * pw4) << 2;
+      const uint16_t* p = L.psum + pr * g.xs + pc;
+      uint2 a = *reinterpret_cast<const uint2*>(p);
+#pragma unroll
+      for (int r = 1; r < 4; r++) {
+        const uint2 b = *reinterpret_cast<const uint2*>(p + r * xq);
+        a.x += b.x;  // 16-bit lanes cannot overflow: 16 * 255 < 65536
+        a.y += b.y;
+      }
+      a.x = (a.x >> 4) & 0x00fe00feu;
+      a.y = (a.y >> 4) & 0x00fe00feu;
+      *reinterpret_cast<uint32_t*>(pvo + pr * g.pw + pc) = __builtin_amdgcn_perm(a.y, a.x, 0x06040200u);
+    }
+  } else {
+    const uint32_t npq = (t.rows >> 2) * g.pw;
+    for (uint32_t q = threadIdx.x; q < npq; q += kThreads) {
+      const uint32_t pr = q / g.pw, pc = q - pr * g.pw;
+      const uint16_t* p = L.psum + pr * g.xs + pc;
+      pvo[q] = (uint8_t)(((p[0] + p[xq] + p[2 * xq] + p[3 * xq]) >> 4) & 0xfe);
+    }
+  }
+}
+
+__device__ __forceinline__ void tile_or_low(const TileLds& L, uint32_t or_low) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) or_low |= __shfl_xor(or_low, off, 64);
+  if ((threadIdx.x & 63) == 0 && or_low) atomicOr(L.s_or, or_low);
+}
+
+// Fused speculative pass.  Workgroup = one tile position x a group of
+// consecutive frames.  The pixel loads of frame f+1 are issued as soon as the
+// registers of frame f are consumed (end of phase A), so HBM reads stay in
+// flight across the LDS phase, the barriers and the stores of frame f.  With
+// CACHE the tile's delta bytes also stay in registers for the whole group
+// (they are the same for every frame).
+template <bool SWAP, bool CACHE>
+__global__ __launch_bounds__(kThreads, 4) void k_fused(
+    const uint16_t* __restrict__ frames, const uint8_t* __restrict__ dhigh,
+    const uint8_t* __restrict__ dlow, const uint8_t* __restrict__ spec_ptr,
+    uint8_t* __restrict__ high, uint8_t* __restrict__ low, uint8_t* __restrict__ pv_raw,
+    uint32_t* __restrict__ anylow, uint16_t* __restrict__ partials, Geom g,
+    uint32_t nframes, uint32_t group) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const TileLds L = tile_lds(smem, g);
+  const uint32_t tid = threadIdx.x;
+  uint32_t tile = blockIdx.x, fg = blockIdx.y;
+  if (g.xcd_map) {
+    const uint32_t b = blockIdx.x, x = b & 7u, j = b >> 3, k = g.tiles >> 3;
+    fg = j / k;
+    tile = x * k + (j - fg * k);
+  }
+  const TileCtx t = tile_ctx(g, tile);
+  const bool with_delta = dhigh != nullptr;
+  const uint32_t spec = *spec_ptr & (with_delta ? 3u : 2u);
+  const bool use_delta = spec & 1, use_cg = spec & 2;
+  const uint4 zero = make_uint4(0, 0, 0, 0);
+
+  uint4 dhc[CACHE ? kMaxIter : 1], dlc[CACHE ? kMaxIter : 1];
+  if (CACHE && use_delta) {
+#pragma unroll
+    for (int it = 0; it < kMaxIter; it++) {
+      const uint32_t seg = tid + it * kThreads;
+      if (seg < t.nseg) {
+        dhc[it] = *reinterpret_cast<const uint4*>(dhigh + t.s + (seg << 4));
+        if (g.shift != 8) dlc[it] = *reinterpret_cast<const uint4*>(dlow + t.s + (seg << 4));
+      }
+    }
+  }
+
+  const uint32_t f0 = fg * group, f1 = min(nframes, f0 + group);
+  uint4 pa[kMaxIter], pb[kMaxIter];  // the frame's pixels of this thread, 16 per pass
+#pragma unroll
+  for (int it = 0; it < kMaxIter; it++) {
+    const uint32_t seg = tid + it * kThreads;
+    if (seg < t.nseg) {
+      const uint16_t* src = frames + (size_t)f0 * g.npix + t.s + (seg << 4);
+      pa[it] = *reinterpret_cast<const uint4*>(src);
+      pb[it] = *reinterpret_cast<const uint4*>(src + 8);
+    }
+  }
+
+  for (uint32_t frame = f0; frame < f1; frame++) {
+    const size_t fbase = (size_t)frame * g.npix;
+    const uint16_t* img = frames + fbase;
+    for (int b = tid; b < kHistFused * 256; b += kThreads) L.hist[b] = 0;
+    if (tid == 0) *L.s_or = 0;
+    if (t.s > 0) load_halo<SWAP>(g, t, L, img, dhigh, use_delta);
+    __syncthreads();
+
+    uint32_t or_low = 0;
+#pragma unroll
+    for (int it = 0; it < kMaxIter; it++) {
+      const uint32_t seg = tid + it * kThreads;
+      if (seg < t.nseg) {
+        const uint32_t o = seg << 4;
+        uint4 dh = zero, dl = zero;
+        if (CACHE) {
+          dh = dhc[it];
+          dl = dlc[it];
+        } else if (use_delta) {
+          dh = *reinterpret_cast<const uint4*>(dhigh + t.s + o);
+          if (g.shift != 8) dl = *reinterpret_cast<const uint4*>(dlow + t.s + o);
+        }
+        seg_phase_a<SWAP, true>(g, t, L, o, pa[it], pb[it], dh, dl, use_delta, use_cg,
+                                high + fbase, low + fbase, &or_low);
+      }
+    }
+    if (frame + 1 < f1) {  // prefetch the next frame of the group
+#pragma unroll
+      for (int it = 0; it < kMaxIter; it++) {
+        const uint32_t seg = tid + it * kThreads;
+        if (seg < t.nseg) {
+          const uint16_t* src = img + g.npix + t.s + (seg << 4);
+          pa[it] = *reinterpret_cast<const uint4*>(src);
+          pb[it] = *reinterpret_cast<const uint4*>(src + 8);
+        }
+      }
+    }
+    tile_or_low(L, or_low);
+    __syncthreads();
+
+#pragma unroll
+    for (int it = 0; it < kMaxIter; it++) {
+      const uint32_t seg = tid + it * kThreads;
+      if (seg < t.nseg) seg_phase_b<true>(g, t, L, seg << 4, use_cg, high + fbase);
+    }
+    tile_preview(g, t, L, pv_raw + (size_t)frame * g.npv);
+    if (tid == 0 && *L.s_or) atomicOr(&anylow[frame], *L.s_or);
+    __syncthreads();
+
+    // partial histograms of this tile: plain 16-bit stores, no atomics
+    uint16_t* ph = partials + ((size_t)frame * g.tiles + tile) * (kHistFused * 256);
+    for (int b = tid; b < kHistFused * 256 / 2; b += kThreads) {
+      const uint2 v = *reinterpret_cast<const uint2*>(L.hist + 2 * b);
+      *reinterpret_cast<uint32_t*>(ph + 2 * b) = (v.x & 0xffffu) | (v.y << 16);
+    }
+    __syncthreads();  // LDS is reused by the next frame
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_stream: the fused speculative pass as a barrier-free streaming kernel.
+//
+// One WAVEFRONT owns one strip (strip_rows image rows) of one frame at a time
+// and pulls strips from a device-side counter.  Per step the wave handles 1024
+// consecutive pixels of the flattened plane, 16 per lane:
+//   - 32-byte coalesced pixel loads (and the delta bytes) come from a 3-deep
+//     register prefetch pipeline: the loads of step t+3 are issued when step t
+//     has consumed its registers, so each wave keeps ~6 KiB of HBM reads in
+//     flight and no load is waited for right after its issue;
+//   - the post-delta high bytes go into the wave's private LDS ring (the last
+//     xs+16+1024 bytes of the plane): the clamped gradient reads its north /
+//     north-west / west neighbours from there.  One wave executes its LDS
+//     operations in order, so no barrier is needed;
+//   - the 4x4 preview boxes are accumulated with LDS adds, one accumulator
+//     row per 4-row group, and written when a group is complete;
+//   - the heuristic samples (i % 15 == 0; i = xs+1+31k) are counted in the
+//     wave's LDS histograms (16-bit bins packed in dwords).
+// ---------------------------------------------------------------------------
+
+constexpr uint32_t kStep = 1024;  // pixels per wave step
+
+typedef short pk16 __attribute__((ext_vector_type(2)));  // two 16-bit lanes in one VGPR
+
+__device__ __forceinline__ pk16 as_pk(uint32_t v) { return __builtin_bit_cast(pk16, v); }
+__device__ __forceinline__ uint32_t as_u32(pk16 v) { return __builtin_bit_cast(uint32_t, v); }
+
+// x - ClampedGradient(n, w, nw) for two pixels at once (16-bit lanes holding
+// 0..255): median(n, w, n + w - nw) = max(min(n,w), min(max(n,w), n+w-nw)).
+// The low byte of each lane is the residual mod 256.
+__device__ __forceinline__ uint32_t cg_res_pk(uint32_t x, uint32_t w, uint32_t n, uint32_t nw) {
+  const pk16 pn = as_pk(n), pw = as_pk(w);
+  const pk16 g = pn + pw - as_pk(nw);
+  const pk16 lo = __builtin_elementwise_min(pn, pw), hi = __builtin_elementwise_max(pn, pw);
+  const pk16 pred = __builtin_elementwise_max(lo, __builtin_elementwise_min(hi, g));
+  return as_u32(as_pk(x) - pred);
+}
+
+// Residuals of 4 pixels (bytes of cur) given the same 4 bytes of the row above
+// (north) and the previous dwords' odd bytes (for west / north-west of byte 0).
+// *xo_prev / *no_prev: {b1, 0, b3, 0} of the previous cur / north dword; updated.
+__device__ __forceinline__ uint32_t cg_res4(uint32_t cur, uint32_t north, uint32_t* xo_prev,
+                                            uint32_t* no_prev) {
+  const uint32_t xe = __builtin_amdgcn_perm(0, cur, 0x0c020c00u);    // {b0, 0, b2, 0}
+  const uint32_t xo = __builtin_amdgcn_perm(0, cur, 0x0c030c01u);    // {b1, 0, b3, 0}
+  const uint32_t ne = __builtin_amdgcn_perm(0, north, 0x0c020c00u);
+  const uint32_t no = __builtin_amdgcn_perm(0, north, 0x0c030c01u);
+  const uint32_t we = __builtin_amdgcn_alignbit(xo, *xo_prev, 16);   // {b-1, 0, b1, 0}
+  const uint32_t nwe = __builtin_amdgcn_alignbit(no, *no_prev, 16);
+  const uint32_t re = cg_res_pk(xe, we, ne, nwe);                    // pixels 0 and 2
+  const uint32_t ro = cg_res_pk(xo, xe, no, ne);                     // pixels 1 and 3
+  *xo_prev = xo;
+  *no_prev = no;
+  return __builtin_amdgcn_perm(ro, re, 0x06020400u);                 // low bytes, pixel order
+}
+
+struct Pre {  // prefetch registers of one step
+  uint4 a, b, dh, dl;
+};
+
+struct StreamCtx {
+  // constant per kernel
+  uint32_t lane, xs, pw, ring_mask, ring_base, nacc, shift;
+  uint8_t* ring;
+  uint32_t* acc;     // [nacc][pw] preview accumulators
+  uint32_t* hist;    // [3][128] packed 16-bit bins
+  bool use_delta, use_cg;
+  // per strip
+  uint32_t s, npx;   // first pixel (frame-flat) and pixel count of the strip
+  const uint16_t* img;
+  const uint8_t *dh, *dl;
+  uint8_t *high_f, *low_f, *pv_f;
+  uint32_t row, col; // position of this lane's segment relative to the strip start
+  uint32_t m15;      // (frame-flat index of the segment) mod 15
+  int q31;           // index - (xs + 1): negative in front of the first CG sample, else mod 31
+  uint32_t or_low;
+  uint32_t groups_done, prow0;
+};
+
+__device__ __forceinline__ uint32_t ring_at(const StreamCtx& c, int o) {
+  return ((uint32_t)(o + (int)c.ring_base)) & c.ring_mask;
+}
+
+__device__ __forceinline__ void hist_inc(uint32_t* hist, uint32_t which, uint32_t bin) {
+  atomicAdd(&hist[which * 128 + (bin >> 1)], 1u << (16 * (bin & 1)));
+}
+
+// DELTA / LOW are the (wave-uniform) conditions "delta predictor speculated" and
+// "a low plane exists" as template parameters, and FAST steps are always full:
+// no control flow around the loads, so that the compiler can keep the three
+// prefetch stages in flight with counted vmcnt waits.
+template <bool FAST, bool DELTA, bool LOW>
+__device__ __forceinline__ void stream_load(const StreamCtx& c, uint32_t it, uint32_t niter,
+                                            Pre* p) {
+  if (FAST) {
+    const uint32_t o = min(it, niter - 1) * kStep + c.lane * 16;  // past the end: reload, unused
+    const uint16_t* src = c.img + c.s + o;
+    p->a = *reinterpret_cast<const uint4*>(src);
+    p->b = *reinterpret_cast<const uint4*>(src + 8);
+    if (DELTA) {
+      p->dh = *reinterpret_cast<const uint4*>(c.dh + c.s + o);
+      if (LOW) p->dl = *reinterpret_cast<const uint4*>(c.dl + c.s + o);
+    }
+  } else {
+    const uint32_t o = it * kStep + c.lane * 16;
+    if (o < c.npx) {
+      const uint16_t* src = c.img + c.s + o;
+      p->a = *reinterpret_cast<const uint4*>(src);
+      p->b = *reinterpret_cast<const uint4*>(src + 8);
+      if (DELTA) {
+        p->dh = *reinterpret_cast<const uint4*>(c.dh + c.s + o);
+        if (LOW) p->dl = *reinterpret_cast<const uint4*>(c.dl + c.s + o);
+      }
+    }
+  }
+}
+
+// Writes the finished 4-row groups' preview pixels and clears their accumulators.
+__device__ __forceinline__ void stream_preview_flush(StreamCtx& c, uint32_t upto_groups) {
+  while (c.groups_done < upto_groups) {
+    const uint32_t slot = c.nacc == 2 ? (c.groups_done & 1u) : c.groups_done % c.nacc;
+    uint32_t* a = c.acc + slot * c.pw;
+    uint8_t* out = c.pv_f + (size_t)(c.prow0 + c.groups_done) * c.pw;
+    if ((c.pw & 3) == 0) {
+      for (uint32_t k = c.lane * 4; k < c.pw; k += 256) {
+        const uint4 v = *reinterpret_cast<const uint4*>(a + k);
+        *reinterpret_cast<uint4*>(a + k) = make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint32_t*>(out + k) = ((v.x >> 4) & 0xfeu) | (((v.y >> 4) & 0xfeu) << 8) |
+                                                (((v.z >> 4) & 0xfeu) << 16) | (((v.w >> 4) & 0xfeu) << 24);
+      }
+    } else {
+      for (uint32_t k = c.lane; k < c.pw; k += 64) {
+        out[k] = (uint8_t)((a[k] >> 4) & 0xfeu);
+        a[k] = 0;
+      }
+    }
+    c.groups_done++;
+  }
+}
+
+// FAST: xs % 16 == 0 and xs >= 256 (a segment never straddles image rows, two
+// preview accumulator rows suffice, the north bytes are one aligned 16-byte read).
+template <bool SWAP, bool FAST, bool DELTA, bool LOW>
+__device__ __forceinline__ void stream_step(StreamCtx& c, uint32_t it, const Pre& p) {
+  const uint32_t o = it * kStep + c.lane * 16;
+  const int S = (int)c.shift;
+  if (FAST || o < c.npx) {
+    uint4 h, l;
+    split4<SWAP>(p.a.x, p.a.y, S, &h.x, &l.x);
+    split4<SWAP>(p.a.z, p.a.w, S, &h.y, &l.y);
+    split4<SWAP>(p.b.x, p.b.y, S, &h.z, &l.z);
+    split4<SWAP>(p.b.z, p.b.w, S, &h.w, &l.w);
+    // preview: 4-pixel sums of the RAW high bytes into the group accumulators (cc:500-509)
+    {
+      const uint32_t q[4] = {__builtin_amdgcn_sad_u8(h.x, 0, 0), __builtin_amdgcn_sad_u8(h.y, 0, 0),
+                             __builtin_amdgcn_sad_u8(h.z, 0, 0), __builtin_amdgcn_sad_u8(h.w, 0, 0)};
+      if (FAST) {
+        uint32_t* a = c.acc + ((c.row >> 2) & 1u) * c.pw + (c.col >> 2);
+#pragma unroll
+        for (int j = 0; j < 4; j++) atomicAdd(a + j, q[j]);
+      } else {
+        uint32_t row = c.row, col = c.col;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          if (col >= c.xs) { col -= c.xs; row++; }
+          atomicAdd(c.acc + ((row >> 2) % c.nacc) * c.pw + (col >> 2), q[j]);
+          col += 4;
+        }
+      }
+    }
+    if (LOW) c.or_low |= l.x | l.y | l.z | l.w;  // RAW low bytes: NO_LOW_BYTES (cc:447)
+    {  // cc:526-531: histogram of high[0::15]
+      const uint32_t j0 = c.m15 ? 15u - c.m15 : 0u;
+      const uint32_t d = j0 >> 2;
+      const uint32_t v = d == 0 ? h.x : d == 1 ? h.y : d == 2 ? h.z : h.w;
+      hist_inc(c.hist, 0, (v >> (8 * (j0 & 3))) & 0xffu);
+      if (j0 == 0) hist_inc(c.hist, 0, h.w >> 24);
+      c.m15 += kStep % 15u;
+      if (c.m15 >= 15u) c.m15 -= 15u;
+    }
+    if (DELTA) {  // cc:534-537
+      h.x = sub4(h.x, p.dh.x); h.y = sub4(h.y, p.dh.y);
+      h.z = sub4(h.z, p.dh.z); h.w = sub4(h.w, p.dh.w);
+      if (LOW) {
+        l.x = sub4(l.x, p.dl.x); l.y = sub4(l.y, p.dl.y);
+        l.z = sub4(l.z, p.dl.z); l.w = sub4(l.w, p.dl.w);
+      }
+    }
+    if (LOW) *reinterpret_cast<uint4*>(c.low_f + c.s + o) = l;
+    const uint32_t a0 = ring_at(c, (int)o);
+    *reinterpret_cast<uint4*>(c.ring + a0) = h;
+    if (!c.use_cg) *reinterpret_cast<uint4*>(c.high_f + c.s + o) = h;
+    __builtin_amdgcn_wave_barrier();  // the reads below see the whole wave's ring writes
+    if (c.use_cg) {  // cc:566-571
+      uint32_t n0, c0;
+      uint4 nv;
+      c0 = *reinterpret_cast<const uint32_t*>(c.ring + ((a0 - 4) & c.ring_mask));
+      if (FAST) {
+        nv = *reinterpret_cast<const uint4*>(c.ring + ((a0 - c.xs) & c.ring_mask));
+        n0 = *reinterpret_cast<const uint32_t*>(c.ring + ((a0 - c.xs - 4) & c.ring_mask));
+      } else {
+        n0 = *reinterpret_cast<const uint32_t*>(c.ring + ((a0 - c.xs - 4) & c.ring_mask));
+        nv.x = *reinterpret_cast<const uint32_t*>(c.ring + ((a0 - c.xs) & c.ring_mask));
+        nv.y = *reinterpret_cast<const uint32_t*>(c.ring + ((a0 - c.xs + 4) & c.ring_mask));
+        nv.z = *reinterpret_cast<const uint32_t*>(c.ring + ((a0 - c.xs + 8) & c.ring_mask));
+        nv.w = *reinterpret_cast<const uint32_t*>(c.ring + ((a0 - c.xs + 12) & c.ring_mask));
+      }
+      uint32_t xo_prev = __builtin_amdgcn_perm(0, c0, 0x0c030c01u);
+      uint32_t no_prev = __builtin_amdgcn_perm(0, n0, 0x0c030c01u);
+      uint4 r;
+      r.x = cg_res4(h.x, nv.x, &xo_prev, &no_prev);
+      r.y = cg_res4(h.y, nv.y, &xo_prev, &no_prev);
+      r.z = cg_res4(h.z, nv.z, &xo_prev, &no_prev);
+      r.w = cg_res4(h.w, nv.w, &xo_prev, &no_prev);
+      // the first xs + 1 bytes of the plane are literals (cc:572): wave-uniform test first
+      if (c.s == 0 && it * kStep < c.xs + 1) {
+        const int nlit = (int)(c.xs + 1) - (int)o;  // literal pixels from the segment start
+        const uint32_t rr[4] = {r.x, r.y, r.z, r.w}, hh[4] = {h.x, h.y, h.z, h.w};
+        uint32_t oo[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int nl = nlit - 4 * k;
+          const uint32_t mask = nl >= 4 ? 0xffffffffu : nl <= 0 ? 0u : (1u << (8 * nl)) - 1u;
+          oo[k] = (hh[k] & mask) | (rr[k] & ~mask);
+        }
+        r = make_uint4(oo[0], oo[1], oo[2], oo[3]);
+      }
+      *reinterpret_cast<uint4*>(c.high_f + c.s + o) = r;
+    }
+    {  // cc:554-562: the CG heuristic's sample at i = xs + 1 + 31 k, if one falls in this segment
+      const uint32_t j1 = c.q31 < 0 ? (uint32_t)(-c.q31) : (c.q31 ? 31u - (uint32_t)c.q31 : 0u);
+      if (j1 < 16) {
+        const uint32_t aj = a0 + j1;
+        const int x = c.ring[aj & c.ring_mask], w = c.ring[(aj - 1) & c.ring_mask];
+        const int n = c.ring[(aj - c.xs) & c.ring_mask], nw = c.ring[(aj - c.xs - 1) & c.ring_mask];
+        hist_inc(c.hist, 1, (uint32_t)x);
+        hist_inc(c.hist, 2, (uint32_t)(x - cg_pred(n, w, nw)) & 0xffu);
+      }
+      if (c.q31 < 0) {
+        c.q31 += (int)kStep;
+        if (c.q31 >= 0) c.q31 %= 31;
+      } else {
+        c.q31 += (int)(kStep % 31u);
+        if (c.q31 >= 31) c.q31 -= 31;
+      }
+    }
+    // advance this lane's (row, col) by one step
+    c.col += kStep % c.xs;
+    c.row += kStep / c.xs;
+    if (c.col >= c.xs) { c.col -= c.xs; c.row++; }
+  }
+  __builtin_amdgcn_wave_barrier();
+  // preview groups completed by this step (wave-uniform)
+  const uint32_t end = min((it + 1) * kStep, c.npx);
+  stream_preview_flush(c, end / (4 * c.xs));
+}
+
+// Kernel arguments kept small on purpose: everything else is derived.
+struct StreamArgs {
+  uint32_t xs, ys, npix, pw, npv;
+  uint32_t strip_rows, strips, ring_fwd, ring_base, nacc, shift, nframes;
+};
+
+template <bool SWAP, bool FAST, bool DELTA, bool LOW>
+__global__ __launch_bounds__(64, 4) void k_stream(
+    const uint16_t* __restrict__ frames, const uint8_t* __restrict__ dhigh,
+    const uint8_t* __restrict__ dlow, const uint8_t* __restrict__ spec_ptr,
+    uint8_t* __restrict__ high, uint8_t* __restrict__ low, uint8_t* __restrict__ pv_raw,
+    uint32_t* __restrict__ anylow, uint16_t* __restrict__ partials,
+    uint32_t* __restrict__ counters, StreamArgs g) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  StreamCtx c;
+  c.lane = threadIdx.x;  // one wavefront per workgroup
+  c.ring = smem;
+  c.acc = reinterpret_cast<uint32_t*>(smem + g.ring_fwd);
+  c.hist = reinterpret_cast<uint32_t*>(smem + g.ring_fwd + g.nacc * g.pw * 4);
+  c.xs = g.xs; c.pw = g.pw; c.ring_mask = g.ring_fwd - 1; c.ring_base = g.ring_base;
+  c.nacc = g.nacc; c.shift = g.shift;
+  const uint32_t spec = *spec_ptr & (dhigh != nullptr ? 3u : 2u);
+  if (DELTA != (bool)(spec & 1)) return;  // the host launches both variants; the other one runs
+  c.use_delta = DELTA;
+  c.use_cg = spec & 2;
+  c.dh = dhigh; c.dl = dlow;
+  for (uint32_t k = c.lane; k < g.nacc * g.pw; k += 64) c.acc[k] = 0;
+  const uint32_t row_l = (c.lane * 16) / g.xs, col_l = (c.lane * 16) % g.xs;
+
+  const uint32_t ntasks = g.nframes * g.strips;
+  for (;;) {
+    uint32_t task = 0;
+    if (c.lane == 0) task = atomicAdd(&counters[6], 1u);
+    task = __builtin_amdgcn_readfirstlane(task);
+    if (task >= ntasks) break;
+    const uint32_t frame = task / g.strips, strip = task - frame * g.strips;
+    const uint32_t row0 = strip * g.strip_rows;
+    const uint32_t rows = min(g.strip_rows, g.ys - row0);
+    const size_t fbase = (size_t)frame * g.npix;
+    c.s = row0 * g.xs;
+    c.npx = rows * g.xs;
+    c.img = frames + fbase;
+    c.high_f = high + fbase;
+    c.low_f = low + fbase;
+    c.pv_f = pv_raw + (size_t)frame * g.npv;
+    c.row = row_l; c.col = col_l;
+    c.m15 = (c.s + c.lane * 16) % 15u;
+    c.q31 = (int)(c.s + c.lane * 16) - (int)(g.xs + 1);
+    if (c.q31 >= 0) c.q31 %= 31;
+    c.or_low = 0;
+    c.groups_done = 0;
+    c.prow0 = row0 >> 2;
+    const uint32_t niter = (c.npx + kStep - 1) / kStep;
+
+    for (uint32_t k = c.lane * 4; k < kHistFused * 128; k += 256)
+      *reinterpret_cast<uint4*>(c.hist + k) = make_uint4(0, 0, 0, 0);
+    if (c.s > 0) {  // halo: post-delta high bytes of the xs+16 pixels in front of the strip
+      const uint32_t hs = c.s - g.xs - 16, ngrp = (g.xs + 16) >> 2;
+      for (uint32_t k = c.lane; k < ngrp; k += 64) {
+        const uint2 v = *reinterpret_cast<const uint2*>(c.img + hs + 4 * k);
+        uint32_t h4, l4;
+        split4<SWAP>(v.x, v.y, (int)g.shift, &h4, &l4);
+        if (c.use_delta) h4 = sub4(h4, *reinterpret_cast<const uint32_t*>(dhigh + hs + 4 * k));
+        *reinterpret_cast<uint32_t*>(c.ring + ring_at(c, (int)(4 * k) - (int)(g.xs + 16))) = h4;
+      }
+    }
+    Pre p0, p1, p2;
+    stream_load<FAST, DELTA, LOW>(c, 0, niter, &p0);
+    stream_load<FAST, DELTA, LOW>(c, 1, niter, &p1);
+    stream_load<FAST, DELTA, LOW>(c, 2, niter, &p2);
+    __builtin_amdgcn_wave_barrier();
+
+    const uint32_t n3 = niter - niter % 3;
+    for (uint32_t it = 0; it < n3; it += 3) {
+      stream_step<SWAP, FAST, DELTA, LOW>(c, it, p0);
+      stream_load<FAST, DELTA, LOW>(c, it + 3, niter, &p0);
+      stream_step<SWAP, FAST, DELTA, LOW>(c, it + 1, p1);
+      stream_load<FAST, DELTA, LOW>(c, it + 4, niter, &p1);
+      stream_step<SWAP, FAST, DELTA, LOW>(c, it + 2, p2);
+      stream_load<FAST, DELTA, LOW>(c, it + 5, niter, &p2);
+    }
+    if (n3 < niter) stream_step<SWAP, FAST, DELTA, LOW>(c, n3, p0);
+    if (n3 + 1 < niter) stream_step<SWAP, FAST, DELTA, LOW>(c, n3 + 1, p1);
+
+    // strip epilogue: NO_LOW accumulator and the partial histograms
+    uint32_t orl = c.or_low;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) orl |= __shfl_xor(orl, off, 64);
+    if (c.lane == 0 && orl) atomicOr(&anylow[frame], orl);
+    uint32_t* ph = reinterpret_cast<uint32_t*>(partials + ((size_t)frame * g.strips + strip) * (kHistFused * 256));
+    for (uint32_t k = c.lane * 4; k < kHistFused * 128; k += 256)
+      *reinterpret_cast<uint4*>(ph + k) = *reinterpret_cast<const uint4*>(c.hist + k);
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
 // EstimateEntropy (cc:235-244) of one 256-bin histogram, one bin per thread.
-__device__ __forceinline__ uint64_t entropy256(const uint32_t* hist,
-                                               uint32_t* scratch) {
-  const uint32_t v = hist[threadIdx.x];
+__device__ __forceinline__ uint64_t entropy_bins(uint32_t v, uint32_t* scratch) {
   const uint32_t sum = block_sum(v, scratch);
   if (sum == 0) return 0;
   const uint32_t lsum = 31 - __clz(sum);
@@ -181,171 +815,214 @@ __device__ __forceinline__ uint64_t entropy256(const uint32_t* hist,
   return (uint64_t)1024 * s / sum;
 }
 
-__global__ __launch_bounds__(kThreads) void k_decide(
-    const uint32_t* __restrict__ hists, uint8_t* __restrict__ decision,
-    int with_delta) {
+// Workspace counters (u32): [0] |list A|, [1] |list B|, [2..5] votes per flags value.
+__global__ __launch_bounds__(kThreads) void k_decide_spec(
+    const uint16_t* __restrict__ partials, const uint8_t* __restrict__ spec_ptr,
+    uint8_t* __restrict__ decision, uint32_t* __restrict__ counters,
+    uint32_t* __restrict__ list_a, uint32_t* __restrict__ list_b, Geom g, int with_delta,
+    int force) {
   __shared__ uint32_t scratch[4];
-  const uint32_t* gh = hists + (size_t)blockIdx.x * kNumHists * 256;
-  // cc:533: E(countd) < E(counta) with countd all in bin 0, i.e. E(counta) > 0.
-  const bool use_delta = with_delta && entropy256(gh, scratch) > 0;
-  const uint32_t* ha = gh + (use_delta ? 3 : 1) * 256;
-  const uint64_t ea = entropy256(ha, scratch);
-  const uint64_t eb = entropy256(ha + 256, scratch);
-  const bool use_cg = eb < ea;  // cc:564
-  if (threadIdx.x == 0)
-    decision[blockIdx.x] = (uint8_t)((use_delta ? 1 : 0) | (use_cg ? 2 : 0));
+  const uint32_t frame = blockIdx.x, tid = threadIdx.x;
+  const uint32_t nparts = g.stream ? g.strips : g.tiles;
+  const uint16_t* ph = partials + (size_t)frame * nparts * (kHistFused * 256);
+  uint32_t v[kHistFused] = {0, 0, 0};
+  for (uint32_t t = 0; t < nparts; t++) {
+#pragma unroll
+    for (int h = 0; h < kHistFused; h++) v[h] += ph[(t * kHistFused + h) * 256 + tid];
+  }
+  const uint32_t spec = *spec_ptr & (with_delta ? 3u : 2u);
+  // cc:533: E(countd) < E(counta); countd has everything in bin 0, E(countd) == 0
+  bool use_delta = with_delta && entropy_bins(v[0], scratch) > 0;
+  if (force >= 0) use_delta = with_delta && (force & 1);  // ablation knob, never set in production
+  if (use_delta != (bool)(spec & 1)) {
+    if (tid == 0) {
+      decision[frame] = 0xff;
+      list_a[atomicAdd(&counters[0], 1u)] = frame;
+    }
+    return;
+  }
+  const uint64_t ea = entropy_bins(v[1], scratch);
+  const uint64_t eb = entropy_bins(v[2], scratch);
+  bool use_cg = eb < ea;  // cc:564
+  if (force >= 0) use_cg = force & 2;
+  if (tid == 0) {
+    const uint32_t dec = (use_delta ? 1u : 0u) | (use_cg ? 2u : 0u);
+    decision[frame] = (uint8_t)dec;
+    atomicAdd(&counters[2 + dec], 1u);
+    if (use_cg != (bool)(spec & 2)) list_b[atomicAdd(&counters[1], 1u)] = frame;
+  }
 }
 
-// ------------------------------------------------------- forward predictor --
+// ---- exact fallback for mis-speculated frames (list driven, grid stride) ----
 
-// One workgroup = one tile of tile_rows rows of one frame, 16 pixels per
-// thread and pass.
-//   phase A: coalesced 32-byte pixel loads -> split -> (delta) -> low plane
-//            stored; high plane into the LDS line buffer; 4-pixel row sums of
-//            the RAW high bytes into LDS for the preview.
-//   phase B: clamped-gradient residual from the LDS line buffer (west, north,
-//            north-west) -> high plane stored; 4x4 preview box from the sums.
+// One thread per sample; all five histograms (both delta hypotheses).
 template <bool SWAP>
-__global__ __launch_bounds__(kThreads) void k_apply(
+__global__ __launch_bounds__(kThreads) void k_stats_list(
+    const uint16_t* __restrict__ frames, const uint8_t* __restrict__ dhigh,
+    const uint32_t* __restrict__ counters, const uint32_t* __restrict__ list_a,
+    uint32_t* __restrict__ hists, Geom g, int with_delta) {
+  __shared__ uint32_t lh[kNumHists * 256];
+  const uint32_t items = counters[0] * g.stat_blocks;
+  for (uint32_t w = blockIdx.x; w < items; w += gridDim.x) {
+    const uint32_t frame = list_a[w / g.stat_blocks], sb = w % g.stat_blocks;
+    const uint16_t* img = frames + (size_t)frame * g.npix;
+    for (int b = threadIdx.x; b < kNumHists * 256; b += kThreads) lh[b] = 0;
+    __syncthreads();
+    const uint32_t stride = g.stat_blocks * kThreads, t0 = sb * kThreads + threadIdx.x;
+    uint32_t h, l;
+    if (with_delta) {  // cc:526-531
+      for (uint32_t k = t0; k < g.nd; k += stride) {
+        split1<SWAP>(img[15u * k], g.shift, &h, &l);
+        atomicAdd(&lh[h], 1u);
+      }
+    }
+    for (uint32_t k = t0; k < g.ncg; k += stride) {  // cc:554-562
+      const uint32_t i = g.xs + 1 + 31u * k;
+      uint32_t x, n, ww, nw;
+      split1<SWAP>(img[i], g.shift, &x, &l);
+      split1<SWAP>(img[i - g.xs], g.shift, &n, &l);
+      split1<SWAP>(img[i - 1], g.shift, &ww, &l);
+      split1<SWAP>(img[i - g.xs - 1], g.shift, &nw, &l);
+      atomicAdd(&lh[1 * 256 + x], 1u);
+      atomicAdd(&lh[2 * 256 + ((x - cg_pred(n, ww, nw)) & 0xffu)], 1u);
+      if (with_delta) {
+        x = (x - dhigh[i]) & 0xffu;
+        n = (n - dhigh[i - g.xs]) & 0xffu;
+        ww = (ww - dhigh[i - 1]) & 0xffu;
+        nw = (nw - dhigh[i - g.xs - 1]) & 0xffu;
+        atomicAdd(&lh[3 * 256 + x], 1u);
+        atomicAdd(&lh[4 * 256 + ((x - cg_pred(n, ww, nw)) & 0xffu)], 1u);
+      }
+    }
+    __syncthreads();
+    uint32_t* gh = hists + (size_t)frame * kNumHists * 256;
+    for (int b = threadIdx.x; b < kNumHists * 256; b += kThreads) {
+      const uint32_t v = lh[b];
+      if (v) atomicAdd(&gh[b], v);
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_decide_list(
+    const uint32_t* __restrict__ hists, uint8_t* __restrict__ decision,
+    uint32_t* __restrict__ counters, const uint32_t* __restrict__ list_a,
+    uint32_t* __restrict__ list_b, int with_delta, int force) {
+  __shared__ uint32_t scratch[4];
+  const uint32_t na = counters[0];
+  for (uint32_t w = blockIdx.x; w < na; w += gridDim.x) {
+    const uint32_t frame = list_a[w];
+    const uint32_t* gh = hists + (size_t)frame * kNumHists * 256;
+    bool use_delta = with_delta && entropy_bins(gh[threadIdx.x], scratch) > 0;
+    if (force >= 0) use_delta = with_delta && (force & 1);
+    const uint32_t* ha = gh + (use_delta ? 3 : 1) * 256;
+    const uint64_t ea = entropy_bins(ha[threadIdx.x], scratch);
+    const uint64_t eb = entropy_bins(ha[256 + threadIdx.x], scratch);
+    bool use_cg = eb < ea;
+    if (force >= 0) use_cg = force & 2;
+    if (threadIdx.x == 0) {
+      const uint32_t dec = (use_delta ? 1u : 0u) | (use_cg ? 2u : 0u);
+      decision[frame] = (uint8_t)dec;
+      atomicAdd(&counters[2 + dec], 1u);
+      list_b[atomicAdd(&counters[1], 1u)] = frame;
+    }
+  }
+}
+
+// Non-speculative tile pass under the frame's TRUE flags.
+template <bool SWAP>
+__global__ __launch_bounds__(kThreads) void k_apply_list(
     const uint16_t* __restrict__ frames, const uint8_t* __restrict__ dhigh,
     const uint8_t* __restrict__ dlow, const uint8_t* __restrict__ decision,
-    uint8_t* __restrict__ high, uint8_t* __restrict__ low,
-    uint8_t* __restrict__ pv_raw, uint32_t* __restrict__ anylow, Geom g) {
+    const uint32_t* __restrict__ counters, const uint32_t* __restrict__ list_b,
+    uint8_t* __restrict__ high, uint8_t* __restrict__ low, uint8_t* __restrict__ pv_raw,
+    uint32_t* __restrict__ anylow, Geom g) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  uint8_t* hbuf = smem;
-  uint16_t* psum = reinterpret_cast<uint16_t*>(smem + g.lds_h_bytes);
-  // last 16 bytes of the dynamic region (no static LDS in front of it: the
-  // 16-byte accesses above need the carve base aligned)
-  uint32_t* s_or = reinterpret_cast<uint32_t*>(smem + g.lds_bytes - 16);
-
-  const uint32_t frame = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
-  const uint32_t row0 = tile * g.tile_rows;
-  const uint32_t rows = min(g.tile_rows, g.ys - row0);
-  const uint32_t s = row0 * g.xs;     // first pixel of the tile (frame-flat)
-  const uint32_t npx = rows * g.xs;   // multiple of 16
-  const uint32_t nseg = npx >> 4;
-  const size_t fbase = (size_t)frame * g.npix;
-  const uint16_t* img = frames + fbase;
-  const uint32_t dec = decision[frame];
-  const bool use_delta = dec & 1, use_cg = dec & 2;
-  const int S = g.shift;
-  if (tid == 0) *s_or = 0;
-  __syncthreads();
-
-  // Halo: post-delta high bytes of the xs+1 pixels in front of the tile.
-  if (use_cg && s > 0) {
-    const uint32_t hs = s - g.xs - 1;
-    for (uint32_t t = tid; t < g.xs + 1; t += kThreads) {
-      uint32_t h, l;
-      split1<SWAP>(img[hs + t], S, &h, &l);
-      if (use_delta) h = (h - dhigh[hs + t]) & 0xffu;
-      hbuf[g.lds_off - (g.xs + 1) + t] = (uint8_t)h;
-    }
-  }
-
-  uint32_t or_low = 0;
-  for (uint32_t seg = tid; seg < nseg; seg += kThreads) {
-    const uint32_t o = seg << 4;
-    const uint4 a = *reinterpret_cast<const uint4*>(img + s + o);
-    const uint4 b = *reinterpret_cast<const uint4*>(img + s + o + 8);
-    uint4 h, l;
-    split4<SWAP>(a.x, a.y, S, &h.x, &l.x);
-    split4<SWAP>(a.z, a.w, S, &h.y, &l.y);
-    split4<SWAP>(b.x, b.y, S, &h.z, &l.z);
-    split4<SWAP>(b.z, b.w, S, &h.w, &l.w);
-    // preview: sums of 4 consecutive RAW high bytes (cc:500-509)
-    uint2 ps;
-    ps.x = __builtin_amdgcn_sad_u8(h.x, 0, 0) | (__builtin_amdgcn_sad_u8(h.y, 0, 0) << 16);
-    ps.y = __builtin_amdgcn_sad_u8(h.z, 0, 0) | (__builtin_amdgcn_sad_u8(h.w, 0, 0) << 16);
-    *reinterpret_cast<uint2*>(psum + (o >> 2)) = ps;
-    if (S != 8) or_low |= l.x | l.y | l.z | l.w;  // cc:396 etc.: RAW low bytes
-    if (use_delta) {  // cc:534-537
-      const uint4 dh = *reinterpret_cast<const uint4*>(dhigh + s + o);
-      h.x = sub4(h.x, dh.x); h.y = sub4(h.y, dh.y);
-      h.z = sub4(h.z, dh.z); h.w = sub4(h.w, dh.w);
-      if (S != 8) {
-        const uint4 dl = *reinterpret_cast<const uint4*>(dlow + s + o);
-        l.x = sub4(l.x, dl.x); l.y = sub4(l.y, dl.y);
-        l.z = sub4(l.z, dl.z); l.w = sub4(l.w, dl.w);
-      }
-    }
-    if (S != 8) *reinterpret_cast<uint4*>(low + fbase + s + o) = l;
-    if (use_cg) {
-      *reinterpret_cast<uint4*>(hbuf + g.lds_off + o) = h;
-    } else {
-      *reinterpret_cast<uint4*>(high + fbase + s + o) = h;
-    }
-  }
-  // NO_LOW_BYTES needs the OR over every raw low byte of the frame (cc:447).
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) or_low |= __shfl_xor(or_low, off, 64);
-  if ((tid & 63) == 0 && or_low) atomicOr(s_or, or_low);
-  __syncthreads();
-  if (tid == 0 && *s_or) atomicOr(&anylow[frame], *s_or);
-
-  if (use_cg) {  // cc:566-572
-    for (uint32_t seg = tid; seg < nseg; seg += kThreads) {
+  const TileLds L = tile_lds(smem, g);
+  const uint32_t tid = threadIdx.x, items = counters[1] * g.tiles;
+  const uint4 zero = make_uint4(0, 0, 0, 0);
+  for (uint32_t w = blockIdx.x; w < items; w += gridDim.x) {
+    const uint32_t frame = list_b[w / g.tiles];
+    const TileCtx t = tile_ctx(g, w % g.tiles);
+    const size_t fbase = (size_t)frame * g.npix;
+    const uint16_t* img = frames + fbase;
+    const uint32_t dec = decision[frame];
+    const bool use_delta = dec & 1, use_cg = dec & 2;
+    if (tid == 0) *L.s_or = 0;
+    if (t.s > 0 && use_cg) load_halo<SWAP>(g, t, L, img, dhigh, use_delta);
+    __syncthreads();
+    uint32_t or_low = 0;
+    for (uint32_t seg = tid; seg < t.nseg; seg += kThreads) {
       const uint32_t o = seg << 4;
-      const uint8_t* cp = hbuf + g.lds_off + o;
-      const uint8_t* np = cp - g.xs;
-      uint32_t c[5], n[5];
-      c[0] = *reinterpret_cast<const uint32_t*>(cp - 4);
-      const uint4 cv = *reinterpret_cast<const uint4*>(cp);
-      c[1] = cv.x; c[2] = cv.y; c[3] = cv.z; c[4] = cv.w;
-#pragma unroll
-      for (int k = 0; k < 5; k++)
-        n[k] = *reinterpret_cast<const uint32_t*>(np - 4 + 4 * k);
-      uint32_t out[4];
-      int wprev = (int)byte_of(c[0], 3), nwprev = (int)byte_of(n[0], 3);
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        uint32_t r = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const int x = (int)byte_of(c[k + 1], j), nn = (int)byte_of(n[k + 1], j);
-          int res = (x - cg_pred(nn, wprev, nwprev)) & 0xff;
-          if (s + o + 4 * k + j < g.xs + 1) res = x;  // literals, cc:572
-          r |= (uint32_t)res << (8 * j);
-          wprev = x;
-          nwprev = nn;
-        }
-        out[k] = r;
+      const uint4 pa = *reinterpret_cast<const uint4*>(img + t.s + o);
+      const uint4 pb = *reinterpret_cast<const uint4*>(img + t.s + o + 8);
+      uint4 dh = zero, dl = zero;
+      if (use_delta) {
+        dh = *reinterpret_cast<const uint4*>(dhigh + t.s + o);
+        if (g.shift != 8) dl = *reinterpret_cast<const uint4*>(dlow + t.s + o);
       }
-      *reinterpret_cast<uint4*>(high + fbase + s + o) =
-          make_uint4(out[0], out[1], out[2], out[3]);
+      seg_phase_a<SWAP, false>(g, t, L, o, pa, pb, dh, dl, use_delta, use_cg, high + fbase,
+                               low + fbase, &or_low);
     }
-  }
-
-  // preview box (cc:500-512): (sum of 16 / 16) & 0xfe
-  const uint32_t xq = g.xs >> 2;  // psum entries per row
-  const uint32_t npq = (rows >> 2) * g.pw;
-  uint8_t* pvo = pv_raw + (size_t)frame * g.npv + (size_t)(row0 >> 2) * g.pw;
-  for (uint32_t q = tid; q < npq; q += kThreads) {
-    const uint32_t pr = q / g.pw, pc = q - pr * g.pw;
-    const uint16_t* p = psum + pr * g.xs + pc;  // 4 rows * xq = xs entries per preview row
-    const uint32_t sum = p[0] + p[xq] + p[2 * xq] + p[3 * xq];
-    pvo[q] = (uint8_t)((sum >> 4) & 0xfe);
+    tile_or_low(L, or_low);
+    __syncthreads();
+    for (uint32_t seg = tid; seg < t.nseg; seg += kThreads)
+      seg_phase_b<false>(g, t, L, seg << 4, use_cg, high + fbase);
+    tile_preview(g, t, L, pv_raw + (size_t)frame * g.npv);
+    if (tid == 0 && *L.s_or) atomicOr(&anylow[frame], *L.s_or);
+    __syncthreads();
   }
 }
 
-// Preview clamped gradient (cc:575-586) + final flags byte.
-__global__ __launch_bounds__(kThreads) void k_preview_finish(
+// Preview clamped gradient (cc:575-586), final flags byte (cc:447-449) and the
+// speculation for the next batch (majority of this batch's decisions).
+__global__ __launch_bounds__(kThreads) void k_finish(
     const uint8_t* __restrict__ pv_raw, const uint8_t* __restrict__ decision,
-    const uint32_t* __restrict__ anylow, uint8_t* __restrict__ preview,
-    uint8_t* __restrict__ flags, Geom g) {
+    const uint32_t* __restrict__ anylow, const uint32_t* __restrict__ counters,
+    uint8_t* __restrict__ preview, uint8_t* __restrict__ flags, uint8_t* __restrict__ spec_ptr,
+    Geom g) {
   const uint32_t frame = blockIdx.y;
   const uint32_t dec = decision[frame];
   const uint8_t* in = pv_raw + (size_t)frame * g.npv;
   uint8_t* out = preview + (size_t)frame * g.npv;
-  const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+  const uint32_t i = (blockIdx.x * kThreads + threadIdx.x) * 4;
   if (i < g.npv) {
-    int x = in[i];
-    if ((dec & 2) && i >= g.pw + 1)
-      x = (x - cg_pred(in[i - g.pw], in[i - 1], in[i - g.pw - 1])) & 0xff;
-    out[i] = (uint8_t)x;
+    if ((g.pw & 3) == 0) {  // npv and pw multiples of 4: dword path
+      const uint32_t c4 = *reinterpret_cast<const uint32_t*>(in + i);
+      uint32_t r4 = c4;
+      if ((dec & 2) && i + 3 >= g.pw + 1) {
+        const uint32_t n4 = *reinterpret_cast<const uint32_t*>(in + i - g.pw);
+        int w = in[i - 1], nw = i > g.pw ? in[i - g.pw - 1] : 0;  // pixel pw is a literal
+        r4 = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int x = (int)byte_of(c4, j), n = (int)byte_of(n4, j);
+          int res = (x - cg_pred(n, w, nw)) & 0xff;
+          if (i + j < g.pw + 1) res = x;
+          r4 |= (uint32_t)res << (8 * j);
+          w = x;
+          nw = n;
+        }
+      }
+      *reinterpret_cast<uint32_t*>(out + i) = r4;
+    } else {
+      for (uint32_t k = i; k < min(i + 4, g.npv); k++) {
+        int x = in[k];
+        if ((dec & 2) && k >= g.pw + 1)
+          x = (x - cg_pred(in[k - g.pw], in[k - 1], in[k - g.pw - 1])) & 0xff;
+        out[k] = (uint8_t)x;
+      }
+    }
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0)
-    flags[frame] = (uint8_t)(dec | (anylow[frame] ? 0 : 4));  // cc:447-449
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    flags[frame] = (uint8_t)(dec | (anylow[frame] ? 0 : 4));
+    if (frame == 0) {  // all decisions are final at this point (stream order)
+      uint32_t best = 0;
+      for (uint32_t k = 1; k < 4; k++)
+        if (counters[2 + k] > counters[2 + best]) best = k;
+      *spec_ptr = (uint8_t)best;
+    }
+  }
 }
 
 // ------------------------------------------------------- inverse predictor --
@@ -478,17 +1155,67 @@ bool make_geom(uint32_t xs, uint32_t ys, int shift, int big_endian, Geom* g,
   g->xs = xs; g->ys = ys; g->npix = xs * ys;
   g->pw = xs / 4; g->ph = ys / 4; g->npv = g->pw * g->ph;
   g->shift = shift; g->swap = big_endian ? 1 : 0;
-  // forward tile: about 16K pixels, whole preview rows
-  uint32_t rows = (16384 / xs) & ~3u;
-  if (rows < 4) rows = 4;
+  // Forward tile: whole preview rows (multiples of 4 image rows), at most
+  // kMaxIter 16-pixel segments per thread, and as few idle threads in the last
+  // pass over the tile as possible (nseg close to a multiple of 256).
+  uint32_t rows = 4;
+  {
+    const uint32_t max_px = kMaxIter * kThreads * 16;
+    double best = -1.0;
+    for (uint32_t r = 4; r <= ys && (uint64_t)r * xs <= max_px; r += 4) {
+      const uint32_t nseg = r * xs / 16, passes = (nseg + kThreads - 1) / kThreads;
+      const double eff = (double)nseg / (passes * kThreads) + 1e-4 * r;  // ties: larger tile
+      if (eff > best) { best = eff; rows = r; }
+    }
+  }
+  if (const char* e = getenv("FPV_TILE_ROWS")) rows = std::max(4u, (uint32_t)atoi(e) & ~3u);
   if (rows > ys) rows = ys;
   g->tile_rows = rows;
   g->tile_px = rows * xs;
   g->tiles = (ys + rows - 1) / rows;
-  g->lds_off = round_up(xs + 4, 16);
+  if (g->tile_px > kMaxIter * kThreads * 16) { *why = kWide; return false; }
+  g->lds_off = round_up(xs + 16, 16);
   g->lds_h_bytes = round_up(g->lds_off + g->tile_px, 16);
-  g->lds_bytes = round_up(g->lds_h_bytes + g->tile_px / 2, 16) + 16;
+  g->lds_hist_off = round_up(g->lds_h_bytes + g->tile_px / 2, 16);
+  g->lds_bytes = g->lds_hist_off + kHistFused * 256 * 4 + 16;
   if (g->lds_bytes > 160 * 1024 - 64) { *why = kWide; return false; }
+  // streaming kernel: strips of about 40K pixels (whole preview rows), one wave each
+  {
+    // Prefer a strip height that divides ys and whose pixel count is a multiple
+    // of the 1024-pixel step (the FAST kernel needs both); about 40K pixels.
+    uint32_t srows = ((40960 + xs - 1) / xs + 3) & ~3u;
+    {
+      uint32_t best = 0;
+      double best_cost = 1e30;
+      for (uint32_t r = 4; r <= ys; r += 4) {
+        if (ys % r || ((uint64_t)r * xs) % kStep) continue;
+        const double px = (double)r * xs;
+        const double cost = px < 40960 ? 40960 / px : px / 40960;  // distance from the target
+        if (cost < best_cost) { best_cost = cost; best = r; }
+      }
+      if (best && best_cost < 4.0) srows = best;
+    }
+    if (const char* e = getenv("FPV_STRIP_ROWS")) srows = std::max(4u, (uint32_t)atoi(e) & ~3u);
+    if (srows > ys) srows = ys;
+    while ((uint64_t)srows * xs > 15u * 60000u && srows > 4) srows -= 4;  // 16-bit histogram bins
+    g->strip_rows = srows;
+    g->strips = (ys + srows - 1) / srows;
+    g->ring_base = round_up(xs + 16, 16);
+    uint32_t rf = 1;
+    while (rf < g->ring_base + kStep) rf <<= 1;
+    g->ring_fwd = rf;
+    g->nacc = (kStep + 4 * xs - 1) / (4 * xs) + 1;
+    g->wave_lds = round_up(rf + g->nacc * g->pw * 4 + kHistFused * 128 * 4, 16);
+    g->stream = g->wave_lds <= 64 * 1024;
+    if (const char* e = getenv("FPV_STREAM")) g->stream = g->stream && atoi(e);
+    uint32_t wpc = (160 * 1024 - 1024) / g->wave_lds;
+    g->stream_waves_per_cu = std::max(1u, std::min(16u, wpc));
+    if (const char* e = getenv("FPV_WAVES_PER_CU")) g->stream_waves_per_cu = std::max(1, atoi(e));
+  }
+  g->xcd_map = 0;
+  if (const char* e = getenv("FPV_XCD_MAP")) g->xcd_map = atoi(e) && (g->tiles % 8 == 0);
+  g->group = 8;
+  if (const char* e = getenv("FPV_GROUP")) g->group = (uint32_t)std::max(1, atoi(e));
   g->nd = (g->npix + 14) / 15;
   g->ncg = g->npix > xs + 1 ? (g->npix - xs - 1 + 30) / 31 : 0;
   uint32_t samples = g->nd + g->ncg;
@@ -518,24 +1245,50 @@ bool make_geom_decoder(uint32_t xs, uint32_t ys, Geom* g, const char** why) {
   return true;
 }
 
-size_t fwd_workspace_bytes(const Geom& g, uint32_t nframes) {
-  size_t b = (size_t)nframes * kNumHists * 256 * 4;  // hists
-  b += round_up(nframes * 4, 256);                    // anylow
-  b += round_up(nframes, 256);                        // decision
-  b += (size_t)nframes * g.npv;                       // pv_raw
-  return b + 256;
+// Workspace layout: [counters | anylow | hists] are zeroed by ONE memset per
+// batch (hists only for the frames of the batch); the rest is fully written by
+// the kernels.  `spec` survives batches.
+size_t fwd_workspace_bytes(const Geom& g, uint32_t max_frames) {
+  size_t b = 256 + round_up(max_frames * 4, 256);                // counters, anylow
+  b += (size_t)max_frames * kNumHists * 256 * 4;                 // hists
+  b += round_up(max_frames, 256);                                // decision
+  b += 2 * (size_t)round_up(max_frames * 4, 256);                // list A, list B
+  b += round_up((size_t)max_frames * g.npv, 256);                // pv_raw
+  b += (size_t)max_frames * std::max(g.tiles, g.strips) * kHistFused * 256 * 2;  // partial histograms (u16)
+  return b + 256 /* spec */ + 256;
 }
 
-void carve_fwd_workspace(const Geom& g, uint32_t nframes, void* base,
+void carve_fwd_workspace(const Geom& g, uint32_t max_frames, void* base,
                          FwdWorkspace* ws) {
   uint8_t* p = static_cast<uint8_t*>(base);
-  ws->hists = reinterpret_cast<uint32_t*>(p);
-  p += (size_t)nframes * kNumHists * 256 * 4;
+  ws->counters = reinterpret_cast<uint32_t*>(p);
+  p += 256;
   ws->anylow = reinterpret_cast<uint32_t*>(p);
-  p += round_up(nframes * 4, 256);
+  p += round_up(max_frames * 4, 256);
+  ws->hists = reinterpret_cast<uint32_t*>(p);
+  ws->zero_fixed = (size_t)(p - static_cast<uint8_t*>(base));
+  p += (size_t)max_frames * kNumHists * 256 * 4;
   ws->decision = p;
-  p += round_up(nframes, 256);
+  p += round_up(max_frames, 256);
+  ws->list_a = reinterpret_cast<uint32_t*>(p);
+  p += round_up(max_frames * 4, 256);
+  ws->list_b = reinterpret_cast<uint32_t*>(p);
+  p += round_up(max_frames * 4, 256);
   ws->pv_raw = p;
+  p += round_up((size_t)max_frames * g.npv, 256);
+  ws->partials = reinterpret_cast<uint16_t*>(p);
+  p += (size_t)max_frames * std::max(g.tiles, g.strips) * kHistFused * 256 * 2;
+  ws->spec = p;
+}
+
+hipError_t init_fwd_workspace(const FwdWorkspace& ws, hipStream_t s) {
+  return hipMemsetAsync(ws.spec, 3, 4, s);  // first guess: delta + CG
+}
+
+hipError_t launch_copy(const void* src, void* dst, size_t bytes, hipStream_t s) {
+  k_copy<<<256 * 8, kThreads, 0, s>>>(static_cast<const uint4*>(src), static_cast<uint4*>(dst),
+                                      bytes / 16);
+  return hipGetLastError();
 }
 
 hipError_t launch_split(const Geom& g, const uint16_t* d_img, uint8_t* d_high,
@@ -563,22 +1316,73 @@ static hipError_t predict_impl(const Geom& g, const uint16_t* d_frames,
                                uint8_t* d_preview, uint8_t* d_flags,
                                hipStream_t s, hipEvent_t* ev) {
   const int with_delta = d_dhigh != nullptr;
+  static const int force = getenv("FPV_DEBUG_FORCE") ? atoi(getenv("FPV_DEBUG_FORCE")) : -1;
   hipError_t e;
-  // hists and anylow are contiguous in the workspace: one memset node
-  size_t zero_bytes = (size_t)nframes * kNumHists * 256 * 4 + round_up(nframes * 4, 256);
-  if ((e = hipMemsetAsync(ws.hists, 0, zero_bytes, s)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(ws.counters, 0, ws.zero_fixed + (size_t)nframes * kNumHists * 256 * 4, s)) !=
+      hipSuccess)
+    return e;
   if (ev) hipEventRecord(ev[0], s);
-  k_stats<SWAP><<<dim3(g.stat_blocks, nframes), kThreads, 0, s>>>(
-      d_frames, d_dhigh, ws.hists, g, with_delta);
+  if (g.stream) {
+    static int ncu = 0;
+    if (!ncu) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+        ncu = prop.multiProcessorCount;
+      if (ncu <= 0) ncu = 256;
+    }
+    const uint32_t ntasks = nframes * g.strips;
+    const uint32_t grid = std::min<uint32_t>(ntasks, (uint32_t)ncu * g.stream_waves_per_cu);
+    StreamArgs a;
+    a.xs = g.xs; a.ys = g.ys; a.npix = g.npix; a.pw = g.pw; a.npv = g.npv;
+    a.strip_rows = g.strip_rows; a.strips = g.strips; a.ring_fwd = g.ring_fwd;
+    a.ring_base = g.ring_base; a.nacc = g.nacc; a.shift = (uint32_t)g.shift; a.nframes = nframes;
+    // FAST needs every step of every strip to be full and a segment never to
+    // straddle image rows.  Both delta variants are launched; the one that does
+    // not match the speculation byte (device memory) exits at once.
+    const bool fast = (g.xs & 15) == 0 && g.nacc == 2 && (g.strip_rows * g.xs) % kStep == 0 &&
+                      g.ys % g.strip_rows == 0;
+#define FPV_LAUNCH_STREAM(F, D, L)                                                            \
+  k_stream<SWAP, F, D, L><<<grid, 64, g.wave_lds, s>>>(d_frames, d_dhigh, d_dlow, ws.spec,   \
+                                                       d_high, d_low, ws.pv_raw, ws.anylow,  \
+                                                       ws.partials, ws.counters, a)
+    const bool lowp = g.shift != 8;
+    if (fast) {
+      if (lowp) { FPV_LAUNCH_STREAM(true, false, true); if (with_delta) FPV_LAUNCH_STREAM(true, true, true); }
+      else { FPV_LAUNCH_STREAM(true, false, false); if (with_delta) FPV_LAUNCH_STREAM(true, true, false); }
+    } else {
+      if (lowp) { FPV_LAUNCH_STREAM(false, false, true); if (with_delta) FPV_LAUNCH_STREAM(false, true, true); }
+      else { FPV_LAUNCH_STREAM(false, false, false); if (with_delta) FPV_LAUNCH_STREAM(false, true, false); }
+    }
+#undef FPV_LAUNCH_STREAM
+  } else {
+    const uint32_t groups = (nframes + g.group - 1) / g.group;
+    static const int cache = getenv("FPV_CACHE_DELTA") ? atoi(getenv("FPV_CACHE_DELTA")) : 0;
+    const dim3 grid = g.xcd_map ? dim3(g.tiles * groups) : dim3(g.tiles, groups);
+    if (cache)
+      k_fused<SWAP, true><<<grid, kThreads, g.lds_bytes, s>>>(
+          d_frames, d_dhigh, d_dlow, ws.spec, d_high, d_low, ws.pv_raw, ws.anylow, ws.partials, g,
+          nframes, g.group);
+    else
+      k_fused<SWAP, false><<<grid, kThreads, g.lds_bytes, s>>>(
+          d_frames, d_dhigh, d_dlow, ws.spec, d_high, d_low, ws.pv_raw, ws.anylow, ws.partials, g,
+          nframes, g.group);
+  }
   if (ev) hipEventRecord(ev[1], s);
-  k_decide<<<nframes, kThreads, 0, s>>>(ws.hists, ws.decision, with_delta);
+  k_decide_spec<<<nframes, kThreads, 0, s>>>(ws.partials, ws.spec, ws.decision, ws.counters,
+                                            ws.list_a, ws.list_b, g, with_delta, force);
   if (ev) hipEventRecord(ev[2], s);
-  k_apply<SWAP><<<dim3(g.tiles, nframes), kThreads, g.lds_bytes, s>>>(
-      d_frames, d_dhigh, d_dlow, ws.decision, d_high, d_low, ws.pv_raw,
+  // exact redo of mis-speculated frames; all three exit at once when the lists are empty
+  k_stats_list<SWAP><<<kListGrid, kThreads, 0, s>>>(d_frames, d_dhigh, ws.counters, ws.list_a,
+                                                   ws.hists, g, with_delta);
+  k_decide_list<<<kListGrid / 4, kThreads, 0, s>>>(ws.hists, ws.decision, ws.counters, ws.list_a,
+                                                  ws.list_b, with_delta, force);
+  k_apply_list<SWAP><<<kListGrid, kThreads, g.lds_bytes, s>>>(
+      d_frames, d_dhigh, d_dlow, ws.decision, ws.counters, ws.list_b, d_high, d_low, ws.pv_raw,
       ws.anylow, g);
   if (ev) hipEventRecord(ev[3], s);
-  k_preview_finish<<<dim3((g.npv + kThreads - 1) / kThreads, nframes), kThreads, 0, s>>>(
-      ws.pv_raw, ws.decision, ws.anylow, d_preview, d_flags, g);
+  k_finish<<<dim3((g.npv / 4 + kThreads) / kThreads, nframes), kThreads, 0, s>>>(
+      ws.pv_raw, ws.decision, ws.anylow, ws.counters, d_preview, d_flags, ws.spec, g);
   if (ev) hipEventRecord(ev[4], s);
   return hipGetLastError();
 }
@@ -590,10 +1394,27 @@ hipError_t launch_predict(const Geom& g, const uint16_t* d_frames,
                           uint8_t* d_flags, hipStream_t s, hipEvent_t* ev) {
   static bool attr_set = false;
   if (!attr_set) {  // tiles above 64 KiB of LDS need the opt-in
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_apply<true>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_apply<false>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+#define FPV_SF(W, F, D, L) reinterpret_cast<const void*>(&k_stream<W, F, D, L>)
+    const void* sf[16] = {
+        FPV_SF(true, true, true, true),    FPV_SF(true, true, true, false),
+        FPV_SF(true, true, false, true),   FPV_SF(true, true, false, false),
+        FPV_SF(true, false, true, true),   FPV_SF(true, false, true, false),
+        FPV_SF(true, false, false, true),  FPV_SF(true, false, false, false),
+        FPV_SF(false, true, true, true),   FPV_SF(false, true, true, false),
+        FPV_SF(false, true, false, true),  FPV_SF(false, true, false, false),
+        FPV_SF(false, false, true, true),  FPV_SF(false, false, true, false),
+        FPV_SF(false, false, false, true), FPV_SF(false, false, false, false)};
+#undef FPV_SF
+    for (const void* f : sf)
+      hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    const void* fns[6] = {reinterpret_cast<const void*>(&k_fused<true, true>),
+                          reinterpret_cast<const void*>(&k_fused<false, true>),
+                          reinterpret_cast<const void*>(&k_fused<true, false>),
+                          reinterpret_cast<const void*>(&k_fused<false, false>),
+                          reinterpret_cast<const void*>(&k_apply_list<true>),
+                          reinterpret_cast<const void*>(&k_apply_list<false>)};
+    for (const void* f : fns)
+      hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
     attr_set = true;
   }
   if (g.swap)

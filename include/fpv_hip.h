@@ -160,6 +160,10 @@ double fpvhip_time_predict_device(fpvhip_ctx *ctx, const void *d_frames,
                                   void *d_high, void *d_low, void *d_preview,
                                   void *d_flags, void *stream, int iters,
                                   double *kernel_ms);
+/* Bench only: `iters` plain 16-B-per-lane device copies of `bytes` bytes on
+ * `stream`; returns elapsed ms.  The measured HBM ceiling kernels are compared with. */
+double fpvhip_time_copy_device(void *d_dst, const void *d_src, size_t bytes,
+                               void *stream, int iters);
 double fpvhip_time_inverse_device(fpvhip_ctx *ctx, const void *d_high,
                                   const void *d_low, const void *d_flags,
                                   uint32_t nframes, void *d_frames,

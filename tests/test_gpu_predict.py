@@ -61,3 +61,27 @@ def test_shapes(fpv, synth, oracle, xs, ys):
     fr = synth.noise_frames(3, xs, ys, seed=3)
     fr[1] = (fr[1] >> 9) + 3000          # smooth-ish: exercises the CG-on branch
     _run_case(fpv, oracle, fr, xs, ys, 0, False, fr[0])
+
+
+def test_partial_batches_reuse_workspace(fpv, synth, oracle):
+    """A context sized for 8 frames is reused for smaller batches whose flags
+    differ (zero low plane after non-zero, CG on after CG off): per-batch state
+    (NO_LOW accumulators, redo lists, speculation) must not leak."""
+    import torch
+    xs, ys = 256, 64
+    noise = synth.noise_frames(8, xs, ys, seed=21)
+    smooth = ((synth.plasma_frames(3, xs, ys, bits=12, seed=2) << 4) & 0xFF00).astype(np.uint16)
+    p = fpv.Predictor(xs, ys, 0, False, max_batch=8)
+    p.set_delta_raw(noise[0])
+    for frames in (noise, smooth, noise[:5], smooth[:1], noise[2:3]):
+        n = frames.shape[0]
+        d = torch.from_numpy(np.ascontiguousarray(frames).reshape(n, -1).view(np.int16)).cuda().view(torch.uint16)
+        high, low, pv, flags = p.predict(d)
+        torch.cuda.synchronize()
+        for k in range(n):
+            eh, el, ep, ef = oracle.predict(frames[k], xs, ys, 0, False, noise[0])
+            assert int(flags[k]) == ef
+            assert np.array_equal(high[k].cpu().numpy(), eh)
+            assert np.array_equal(low[k].cpu().numpy(), el)
+            assert np.array_equal(pv[k].cpu().numpy(), ep)
+    p.close()

@@ -34,6 +34,7 @@ struct Geom {
   uint32_t nd, ncg;             // sample counts of the two heuristics
   uint32_t stat_blocks;         // workgroups per frame of the stats kernel
   uint32_t ring;                // inverse kernel: LDS ring size (power of two)
+  uint32_t inv_ring;            // fast inverse kernel: ring size in pixels (power of two)
   int32_t shift, swap;          // Frame ctor arguments (swap = big_endian on LE host)
   int32_t xcd_map;              // forward kernel: XCD-partitioned tile ranges (speed only)
   int32_t fwd_ok;               // forward kernels usable (dims multiples of 4, LDS fits)

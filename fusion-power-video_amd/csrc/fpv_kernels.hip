@@ -474,6 +474,30 @@ __global__ __launch_bounds__(kThreads, 4) void k_fused(
 
 constexpr uint32_t kStep = 1024;  // pixels per wave step
 
+// Streaming accesses: pixels are read once and planes are written once, so they
+// are marked non-temporal to keep the (re-used) delta planes resident in L2.
+#ifndef FPV_NT
+#define FPV_NT 1
+#endif
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ld_stream(const void* p) {
+#if FPV_NT
+  const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+  return make_uint4(v.x, v.y, v.z, v.w);
+#else
+  return *reinterpret_cast<const uint4*>(p);
+#endif
+}
+__device__ __forceinline__ void st_stream(void* p, uint4 v) {
+#if FPV_NT
+  u32x4 t;
+  t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+  __builtin_nontemporal_store(t, reinterpret_cast<u32x4*>(p));
+#else
+  *reinterpret_cast<uint4*>(p) = v;
+#endif
+}
+
 typedef short pk16 __attribute__((ext_vector_type(2)));  // two 16-bit lanes in one VGPR
 
 __device__ __forceinline__ pk16 as_pk(uint32_t v) { return __builtin_bit_cast(pk16, v); }
@@ -549,8 +573,8 @@ __device__ __forceinline__ void stream_load(const StreamCtx& c, uint32_t it, uin
   if (FAST) {
     const uint32_t o = min(it, niter - 1) * kStep + c.lane * 16;  // past the end: reload, unused
     const uint16_t* src = c.img + c.s + o;
-    p->a = *reinterpret_cast<const uint4*>(src);
-    p->b = *reinterpret_cast<const uint4*>(src + 8);
+    p->a = ld_stream(src);
+    p->b = ld_stream(src + 8);
     if (DELTA) {
       p->dh = *reinterpret_cast<const uint4*>(c.dh + c.s + o);
       if (LOW) p->dl = *reinterpret_cast<const uint4*>(c.dl + c.s + o);
@@ -640,10 +664,10 @@ __device__ __forceinline__ void stream_step(StreamCtx& c, uint32_t it, const Pre
         l.z = sub4(l.z, p.dl.z); l.w = sub4(l.w, p.dl.w);
       }
     }
-    if (LOW) *reinterpret_cast<uint4*>(c.low_f + c.s + o) = l;
+    if (LOW) st_stream(c.low_f + c.s + o, l);
     const uint32_t a0 = ring_at(c, (int)o);
     *reinterpret_cast<uint4*>(c.ring + a0) = h;
-    if (!c.use_cg) *reinterpret_cast<uint4*>(c.high_f + c.s + o) = h;
+    if (!c.use_cg) st_stream(c.high_f + c.s + o, h);
     __builtin_amdgcn_wave_barrier();  // the reads below see the whole wave's ring writes
     if (c.use_cg) {  // cc:566-571
       uint32_t n0, c0;
@@ -679,7 +703,7 @@ __device__ __forceinline__ void stream_step(StreamCtx& c, uint32_t it, const Pre
         }
         r = make_uint4(oo[0], oo[1], oo[2], oo[3]);
       }
-      *reinterpret_cast<uint4*>(c.high_f + c.s + o) = r;
+      st_stream(c.high_f + c.s + o, r);
     }
     {  // cc:554-562: the CG heuristic's sample at i = xs + 1 + 31 k, if one falls in this segment
       const uint32_t j1 = c.q31 < 0 ? (uint32_t)(-c.q31) : (c.q31 ? 31u - (uint32_t)c.q31 : 0u);
@@ -1137,6 +1161,155 @@ __global__ __launch_bounds__(64) void k_inverse(
   }
 }
 
+// Fast inverse (xs % 4 == 0, npix % 4 == 0, xs >= 256).  Still one wavefront
+// per frame and still a serial chain -- that is the algorithm (cc:327-332) --
+// but the chain is cut down to three dependent VALU instructions per pixel.
+// Values are kept as v << 8 in 16-bit lanes, so that "+ r mod 256" is one
+// 16-bit add that wraps by itself:
+//
+//     T = W + D (32-bit, d = n - nw may be negative);  M = med3_i32(N, W, T);
+//     X = add_u16(M, R)
+//
+// Everything that does not depend on the running value W is prepared for a
+// whole 256-pixel chunk by all 64 lanes in parallel and left in LINEAR LDS
+// arrays (one dword per pixel: N, D, R), so the chain issues only 128-bit LDS
+// reads with immediate offsets, the three VALU ops and one 128-bit LDS write
+// per four pixels -- no address arithmetic, no branches.  All lanes run the
+// chain redundantly on wave-uniform data; the other phases are data parallel.
+constexpr uint32_t kInvC = 256;
+
+__device__ __forceinline__ uint32_t inv_px(uint32_t n, uint32_t w, uint32_t d, uint32_t r) {
+  const int t = (int)w + (int)d;
+  const int lo = min((int)n, (int)w), hi = max((int)n, (int)w);
+  const int md = max(lo, min(hi, t));                 // one v_med3_i32
+  return as_u32(as_pk((uint32_t)md) + as_pk(r));      // v_pk_add_u16: low lane wraps mod 2^16
+}
+
+__global__ __launch_bounds__(64) void k_inverse_fast(
+    const uint8_t* __restrict__ high, const uint8_t* __restrict__ low,
+    const uint8_t* __restrict__ dhigh, const uint8_t* __restrict__ dlow,
+    const uint8_t* __restrict__ flags, uint16_t* __restrict__ frames, Geom g) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const uint32_t frame = blockIdx.x, lane = threadIdx.x;
+  const size_t fbase = (size_t)frame * g.npix;
+  const uint8_t* hp = high + fbase;
+  const uint8_t* lp = low ? low + fbase : nullptr;
+  uint16_t* outp = frames + fbase;
+  const uint32_t f = flags[frame];
+  const bool use_delta = (f & 1) && dhigh, use_cg = f & 2, no_low = (f & 4) || !lp;
+  const uint32_t xs = g.xs, npix = g.npix;
+
+  if (!use_cg) {  // no chain: delta^-1 + recombine, 16 pixels per lane and step
+    for (uint32_t o = lane * 16; o < npix; o += 1024) {
+      uint4 h = *reinterpret_cast<const uint4*>(hp + o);
+      uint4 l = no_low ? make_uint4(0, 0, 0, 0) : *reinterpret_cast<const uint4*>(lp + o);
+      if (use_delta) {
+        const uint4 dh = *reinterpret_cast<const uint4*>(dhigh + o);
+        const uint4 dl = *reinterpret_cast<const uint4*>(dlow + o);
+        h.x = add4(h.x, dh.x); h.y = add4(h.y, dh.y); h.z = add4(h.z, dh.z); h.w = add4(h.w, dh.w);
+        l.x = add4(l.x, dl.x); l.y = add4(l.y, dl.y); l.z = add4(l.z, dl.z); l.w = add4(l.w, dl.w);
+      }
+      uint4 a, b;
+      a.x = __builtin_amdgcn_perm(h.x, l.x, 0x05010400u); a.y = __builtin_amdgcn_perm(h.x, l.x, 0x07030602u);
+      a.z = __builtin_amdgcn_perm(h.y, l.y, 0x05010400u); a.w = __builtin_amdgcn_perm(h.y, l.y, 0x07030602u);
+      b.x = __builtin_amdgcn_perm(h.z, l.z, 0x05010400u); b.y = __builtin_amdgcn_perm(h.z, l.z, 0x07030602u);
+      b.z = __builtin_amdgcn_perm(h.w, l.w, 0x05010400u); b.w = __builtin_amdgcn_perm(h.w, l.w, 0x07030602u);
+      *reinterpret_cast<uint4*>(outp + o) = a;
+      *reinterpret_cast<uint4*>(outp + o + 8) = b;
+    }
+    return;
+  }
+
+  // LDS: ring of reconstructed values (v << 8, one dword per pixel), then the
+  // chunk's linear operand arrays and result array.
+  uint32_t* xr = reinterpret_cast<uint32_t*>(smem);
+  const uint32_t m = g.inv_ring - 1;  // ring size in pixels (power of two)
+  uint32_t* nn = xr + g.inv_ring;
+  uint32_t* dd = nn + kInvC;
+  uint32_t* rr = dd + kInvC;
+  uint32_t* xx = rr + kInvC;
+  uint32_t w = 0;
+
+  for (uint32_t c0 = 0; c0 < npix; c0 += kInvC) {
+    const uint32_t cn = min(kInvC, npix - c0);
+    const uint32_t j = lane * 4, i = c0 + j;
+    // prep (all lanes, 4 pixels each)
+    if (j < cn) {
+      const uint32_t r4 = *reinterpret_cast<const uint32_t*>(hp + i);
+      *reinterpret_cast<uint4*>(rr + j) =
+          make_uint4((r4 << 8) & 0xff00u, r4 & 0xff00u, (r4 >> 8) & 0xff00u, (r4 >> 16) & 0xff00u);
+      if (i >= xs + 4) {  // earlier groups go through the head path below
+        const uint4 n4 = *reinterpret_cast<const uint4*>(xr + ((i - xs) & m));
+        const uint32_t nw0 = xr[(i - xs - 1) & m];
+        *reinterpret_cast<uint4*>(nn + j) = n4;
+        *reinterpret_cast<uint4*>(dd + j) = make_uint4(n4.x - nw0, n4.y - n4.x, n4.z - n4.y, n4.w - n4.z);
+      }
+    }
+    __syncthreads();
+    // chain (wave-uniform)
+    uint32_t jj = 0;
+    for (; jj < cn && c0 + jj < xs + 4; jj += 4) {  // head: literals (cc:327) and the first group
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t ii = c0 + jj + k;
+        uint32_t x = rr[jj + k];
+        if (ii >= xs + 1) {
+          const uint32_t n = xr[(ii - xs) & m], nw = xr[(ii - xs - 1) & m];
+          x = inv_px(n, w, n - nw, x);
+        }
+        xr[ii & m] = x;  // the head's own north / north-west come from the ring
+        xx[jj + k] = x;
+        w = x;
+      }
+    }
+    if (jj == 0 && cn == kInvC) {  // the common case: a whole chunk, fully unrolled
+#pragma unroll
+      for (int q = 0; q < (int)kInvC; q += 4) {
+        const uint4 n4 = *reinterpret_cast<const uint4*>(nn + q);
+        const uint4 d4 = *reinterpret_cast<const uint4*>(dd + q);
+        const uint4 r4 = *reinterpret_cast<const uint4*>(rr + q);
+        uint4 x4;
+        x4.x = inv_px(n4.x, w, d4.x, r4.x);
+        x4.y = inv_px(n4.y, x4.x, d4.y, r4.y);
+        x4.z = inv_px(n4.z, x4.y, d4.z, r4.z);
+        x4.w = inv_px(n4.w, x4.z, d4.w, r4.w);
+        w = x4.w;
+        *reinterpret_cast<uint4*>(xx + q) = x4;
+      }
+    } else {
+      for (; jj < cn; jj += 4) {
+        const uint4 n4 = *reinterpret_cast<const uint4*>(nn + jj);
+        const uint4 d4 = *reinterpret_cast<const uint4*>(dd + jj);
+        const uint4 r4 = *reinterpret_cast<const uint4*>(rr + jj);
+        uint4 x4;
+        x4.x = inv_px(n4.x, w, d4.x, r4.x);
+        x4.y = inv_px(n4.y, x4.x, d4.y, r4.y);
+        x4.z = inv_px(n4.z, x4.y, d4.z, r4.z);
+        x4.w = inv_px(n4.w, x4.z, d4.w, r4.w);
+        w = x4.w;
+        *reinterpret_cast<uint4*>(xx + jj) = x4;
+      }
+    }
+    __syncthreads();
+    // output (all lanes, 4 pixels each): ring update, delta^-1 + recombine (cc:335-344)
+    if (j < cn) {
+      const uint4 x4 = *reinterpret_cast<const uint4*>(xx + j);
+      *reinterpret_cast<uint4*>(xr + (i & m)) = x4;
+      uint32_t h4 = (x4.x >> 8) | (x4.y & 0xff00u) | ((x4.z & 0xff00u) << 8) | ((x4.w & 0xff00u) << 16);
+      uint32_t l4 = no_low ? 0u : *reinterpret_cast<const uint32_t*>(lp + i);
+      if (use_delta) {
+        h4 = add4(h4, *reinterpret_cast<const uint32_t*>(dhigh + i));
+        l4 = add4(l4, *reinterpret_cast<const uint32_t*>(dlow + i));
+      }
+      uint2 o;
+      o.x = __builtin_amdgcn_perm(h4, l4, 0x05010400u);
+      o.y = __builtin_amdgcn_perm(h4, l4, 0x07030602u);
+      *reinterpret_cast<uint2*>(outp + i) = o;
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------- host side ---
@@ -1224,6 +1397,7 @@ bool make_geom(uint32_t xs, uint32_t ys, int shift, int big_endian, Geom* g,
   uint32_t ring = 1;
   while (ring < xs + 1 + kInvChunk + 4) ring <<= 1;
   g->ring = ring;
+  { uint32_t ir = 1; while (ir < xs + 8 + kInvC) ir <<= 1; g->inv_ring = ir; }
   g->fwd_ok = 1;
   return true;
 }
@@ -1241,6 +1415,7 @@ bool make_geom_decoder(uint32_t xs, uint32_t ys, Geom* g, const char** why) {
   while (ring < xs + 1 + kInvChunk + 4) ring <<= 1;
   if (ring > 128 * 1024) { *why = kWide; return false; }
   g->ring = ring;
+  { uint32_t ir = 1; while (ir < xs + 8 + kInvC) ir <<= 1; g->inv_ring = ir; }
   g->fwd_ok = 0;
   return true;
 }
@@ -1434,9 +1609,14 @@ hipError_t launch_inverse(const Geom& g, const uint8_t* d_high,
                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inverse<false>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inverse_fast),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
     attr_set = true;
   }
-  if ((g.xs & 3) == 0 && (g.npix & 3) == 0)
+  if ((g.xs & 3) == 0 && (g.npix & 3) == 0 && g.xs >= kInvC && !getenv("FPV_INVERSE_SLOW"))
+    k_inverse_fast<<<nframes, 64, (g.inv_ring + 4 * kInvC) * 4, s>>>(d_high, d_low, d_dhigh, d_dlow,
+                                                                     d_flags, d_frames, g);
+  else if ((g.xs & 3) == 0 && (g.npix & 3) == 0)
     k_inverse<true><<<nframes, 64, g.ring, s>>>(d_high, d_low, d_dhigh, d_dlow,
                                                 d_flags, d_frames, g);
   else

@@ -79,7 +79,7 @@ tests/shim/fpvhip_oracle_shim.o: tests/shim/fpvhip_oracle_shim.c include/fpv_hip
 tests/shim/fpv_oracle.o: oracle/fpv_oracle.c oracle/fpv_oracle.h
 	gcc -std=c99 -O2 -fPIC -Wall -Wextra -Ioracle -I$(BROTLI_I) -c $< -o $@
 tests/shim/libfpv_amd_cpushim.so: tests/shim/fpvhip_oracle_shim.o tests/shim/fpv_oracle.o $(HOST_SRC) $(HOST_HDR)
-	$(CXX) $(CXXFLAGS) -shared $(HOST_SRC) tests/shim/fpvhip_oracle_shim.o tests/shim/fpv_oracle.o \
+	$(CXX) $(CXXFLAGS) -shared -Wl,-Bsymbolic $(HOST_SRC) tests/shim/fpvhip_oracle_shim.o tests/shim/fpv_oracle.o \
 	    $(BROTLI) -o $@
 
 clean:

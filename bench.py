@@ -109,7 +109,8 @@ def main():
 
     # HIP-event timing on the launch stream: whole pipeline and per kernel
     ev_ms, kernel_ms = pred.time_predict(d_frames, out, max(args.steps, 5), per_kernel=True)
-    names = ["k_fused", "k_decide_spec", "redo_lists(3 launches)", "k_finish"]
+    names = ["k_stream", "k_decide_spec", "redo_lists(3 launches)", "k_finish"]
+    copy_gbps = pkg.copy_bandwidth_GBps(1 << 30, 5, device=local_rank) if rank == 0 else 0.0
     dom = int(np.argmax(kernel_ms))
     dom_s = kernel_ms[dom] / 1e3
     achieved = n * ALG_BYTES_PER_FRAME / dom_s / 1e9
@@ -132,12 +133,16 @@ def main():
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": None,
-                         "algorithmic_bytes_per_launch": n * ALG_BYTES_PER_FRAME},
+                         "algorithmic_bytes_per_launch": n * ALG_BYTES_PER_FRAME,
+                         "measured_copy_GBps": round(copy_gbps, 1)},
         }
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):
             try:
-                res["roofline"]["traffic"] = json.load(open(tf)).get(names[dom])
+                t = json.load(open(tf)).get(names[dom])
+                if t and n == NFRAMES:   # PMC bytes per launch of the same 1000-frame workload
+                    res["roofline"]["traffic"] = t["bytes_per_launch"]
+                    res["roofline"]["traffic_source"] = t["source"]
             except Exception:
                 pass
         if world == 1 and not args.no_cpu_baseline:

@@ -80,7 +80,7 @@ def hip_lib():
         path = os.path.join(LIBDIR, "libfpvhip.so")
         if not os.path.exists(path):
             raise FpvError(f"{path} is missing: run `make product` (no CPU fallback exists)")
-        _hip = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+        _hip = ctypes.CDLL(path)
         _declare_hip(_hip)
     return _hip
 

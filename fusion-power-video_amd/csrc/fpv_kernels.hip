@@ -1382,7 +1382,7 @@ bool make_geom(uint32_t xs, uint32_t ys, int shift, int big_endian, Geom* g,
     g->stream = g->wave_lds <= 64 * 1024;
     if (const char* e = getenv("FPV_STREAM")) g->stream = g->stream && atoi(e);
     uint32_t wpc = (160 * 1024 - 1024) / g->wave_lds;
-    g->stream_waves_per_cu = std::max(1u, std::min(16u, wpc));
+    g->stream_waves_per_cu = std::max(1u, std::min(12u, wpc));  // measured: 8-12 beat 16 (memory-system contention)
     if (const char* e = getenv("FPV_WAVES_PER_CU")) g->stream_waves_per_cu = std::max(1, atoi(e));
   }
   g->xcd_map = 0;

@@ -23,10 +23,10 @@ REF      ?= /root/reference
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -I$(CSRC) -Wall -Wno-unused-value -Wno-unused-result
 CXXFLAGS := -std=c++14 -O2 -fPIC -Iinclude -I$(CSRC) -I$(BROTLI_I) -Wall -Wextra -pthread
 
-HOST_SRC := $(CSRC)/fpv_host.cc $(CSRC)/fpv_decoders.cc $(CSRC)/fpv_c_api.cc
-HOST_HDR := include/fusion_power_video.h include/fpv_hip.h include/fpv_c_api.h $(CSRC)/fpv_host_internal.h
+HOST_SRC := $(CSRC)/fpv_host.cc $(CSRC)/fpv_decoders.cc $(CSRC)/fpv_frame.cc $(CSRC)/fpv_c_api.cc
+HOST_HDR := include/fusion_power_video.h include/fpv_hip.h include/fpv_c_api.h $(CSRC)/fpv_host_internal.h $(CSRC)/fpv_frame_capi.inc
 
-all: product tools oracle shim refcli
+all: product tools oracle shim refcli refcb
 
 product: $(LIBDIR)/libfpvhip.so $(LIBDIR)/libfpv_amd.so
 
@@ -62,9 +62,30 @@ $(BINDIR)/ref_%: build/refsrc/%.cc $(LIBDIR)/libfpv_amd.so include/fusion_power_
 	@mkdir -p $(BINDIR)
 	$(CXX) -std=c++14 -O2 -w -Iinclude $< -L$(LIBDIR) -lfpv_amd -lfpvhip -lpthread \
 	    -Wl,-rpath,'$$ORIGIN/../../$(LIBDIR)' -Wl,-rpath,$(ROCM_LIB) -o $@
+
+# The upstream columnar_batch adapter (uses the Frame API) compiled unchanged:
+# its sources say #include "../fusion_power_video.h", so a symlink to OUR
+# header sits one level above the symlinked sources.
+CB := columnar_batch
+refcb: $(BINDIR)/ref_columnar_batch_decoder_test $(BINDIR)/ref_columnar_batch_encoder_test
+build/refsrc/fusion_power_video.h: include/fusion_power_video.h
+	@mkdir -p build/refsrc
+	ln -sf ../../include/fusion_power_video.h $@
+build/refsrc/$(CB)/.linked: $(wildcard $(REF)/$(CB)/*) build/refsrc/fusion_power_video.h
+	@mkdir -p build/refsrc/$(CB)
+	for f in $(REF)/$(CB)/*.cc $(REF)/$(CB)/*.h; do ln -sf $$f build/refsrc/$(CB)/; done
+	touch $@
+$(BINDIR)/ref_columnar_batch_%_test: build/refsrc/$(CB)/.linked $(LIBDIR)/libfpv_amd.so
+	@mkdir -p $(BINDIR)
+	$(CXX) -std=c++17 -O2 -w -I$(BROTLI_I) build/refsrc/$(CB)/columnar_batch.cc \
+	    build/refsrc/$(CB)/columnar_batch_encoder.cc build/refsrc/$(CB)/columnar_batch_decoder.cc \
+	    build/refsrc/$(CB)/columnar_batch_$*_test.cc -L$(LIBDIR) -lfpv_amd -lfpvhip $(BROTLI) -lpthread \
+	    -Wl,-rpath,'$$ORIGIN/../../$(LIBDIR)' -Wl,-rpath,$(ROCM_LIB) -o $@
 else
 refcli:
 	@echo "refcli: $(REF) not present, skipped"
+refcb:
+	@echo "refcb: $(REF) not present, skipped"
 endif
 
 oracle:
@@ -86,4 +107,4 @@ clean:
 	rm -rf $(LIBDIR) build tests/shim/*.so tests/shim/*.o
 	$(MAKE) -C oracle clean
 
-.PHONY: all product tools oracle shim refcli clean
+.PHONY: all product tools oracle shim refcli refcb clean

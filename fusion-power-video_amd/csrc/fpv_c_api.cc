@@ -129,4 +129,8 @@ void fpvc_unextract(const uint16_t* img, size_t xs, size_t ys, int shift,
   fpvc::UnextractFrame(img, xs, ys, shift, big_endian != 0, out);
 }
 
+#define FPV_FN(name) fpvc_##name
+#include "fpv_frame_capi.inc"
+#undef FPV_FN
+
 }  // extern "C"

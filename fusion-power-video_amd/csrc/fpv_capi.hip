@@ -224,7 +224,7 @@ int fpvhip_set_delta_raw(fpvhip_ctx* c, const uint16_t* delta_raw) {
   if (!c->g.fwd_ok) return fail(c, "decoder-only context");
   HIPOK(c, hipSetDevice(c->device));
   HIPOK(c, hipMemcpy(c->d_dtmp, delta_raw, (size_t)c->g.npix * 2, hipMemcpyHostToDevice));
-  HIPOK(c, fpvhip::launch_split(c->g, c->d_dtmp, c->d_dhigh, c->d_dlow, nullptr));
+  HIPOK(c, fpvhip::launch_split(c->g, c->d_dtmp, c->d_dhigh, c->d_dlow, nullptr, nullptr));
   HIPOK(c, hipStreamSynchronize(nullptr));
   c->have_delta = true;
   return 0;
@@ -252,13 +252,45 @@ int fpvhip_set_delta_planes(fpvhip_ctx* c, const uint8_t* high, const uint8_t* l
   return 0;
 }
 
+int fpvhip_split_frame(fpvhip_ctx* c, const uint16_t* img, uint8_t* high, uint8_t* low,
+                       int* no_low) {
+  if (!c || !img || !high || !no_low) return fail(c, "null argument");
+  if (!c->g.fwd_ok || c->slots.empty()) return fail(c, "needs a forward context with a slot");
+  Slot& s = c->slots[0];
+  const size_t np = c->g.npix;
+  HIPOK(c, hipSetDevice(c->device));
+  HIPOK(c, hipMemcpyAsync(s.d_pix, img, np * 2, hipMemcpyHostToDevice, s.stream));
+  HIPOK(c, hipMemsetAsync(s.ws.anylow, 0, 4, s.stream));
+  HIPOK(c, fpvhip::launch_split(c->g, s.d_pix, s.d_high, s.d_low, s.ws.anylow, s.stream));
+  HIPOK(c, hipMemcpyAsync(high, s.d_high, np, hipMemcpyDeviceToHost, s.stream));
+  if (low && c->g.shift != 8)
+    HIPOK(c, hipMemcpyAsync(low, s.d_low, np, hipMemcpyDeviceToHost, s.stream));
+  uint32_t any = 0;
+  HIPOK(c, hipMemcpyAsync(&any, s.ws.anylow, 4, hipMemcpyDeviceToHost, s.stream));
+  HIPOK(c, hipStreamSynchronize(s.stream));
+  *no_low = any == 0;
+  return 0;
+}
+
 uint16_t* fpvhip_stage_in(fpvhip_ctx* c, uint32_t slot, uint32_t k) {
   if (check_slot(c, slot) || k >= c->max_batch) return nullptr;
   return c->slots[slot].h_pix + (size_t)k * c->g.npix;
 }
 
-int fpvhip_predict_submit(fpvhip_ctx* c, uint32_t slot, uint32_t nframes,
-                          int with_delta) {
+static int predict_submit_impl(fpvhip_ctx* c, uint32_t slot, uint32_t nframes, int with_delta,
+                               bool from_planes);
+
+int fpvhip_predict_submit(fpvhip_ctx* c, uint32_t slot, uint32_t nframes, int with_delta) {
+  return predict_submit_impl(c, slot, nframes, with_delta, false);
+}
+
+int fpvhip_predict_planes_submit(fpvhip_ctx* c, uint32_t slot, uint32_t nframes, int with_delta) {
+  if (c && (c->g.shift != 0 || c->g.swap)) return fail(c, "planes input needs a shift 0 / little-endian context");
+  return predict_submit_impl(c, slot, nframes, with_delta, true);
+}
+
+static int predict_submit_impl(fpvhip_ctx* c, uint32_t slot, uint32_t nframes, int with_delta,
+                               bool from_planes) {
   if (check_slot(c, slot)) return -1;
   if (nframes == 0 || nframes > c->max_batch) return fail(c, "bad nframes %u", nframes);
   if (with_delta && !c->have_delta) return fail(c, "delta frame not set");
@@ -266,7 +298,13 @@ int fpvhip_predict_submit(fpvhip_ctx* c, uint32_t slot, uint32_t nframes,
   Slot& s = c->slots[slot];
   const size_t np = c->g.npix, nv = c->g.npv;
   HIPOK(c, hipSetDevice(c->device));
-  HIPOK(c, hipMemcpyAsync(s.d_pix, s.h_pix, nframes * np * 2, hipMemcpyHostToDevice, s.stream));
+  if (from_planes) {  // planes staged in h_high / h_low -> pixels on the device
+    HIPOK(c, hipMemcpyAsync(s.d_high, s.h_high, nframes * np, hipMemcpyHostToDevice, s.stream));
+    HIPOK(c, hipMemcpyAsync(s.d_low, s.h_low, nframes * np, hipMemcpyHostToDevice, s.stream));
+    HIPOK(c, fpvhip::launch_interleave(s.d_high, s.d_low, s.d_pix, nframes * np, s.stream));
+  } else {
+    HIPOK(c, hipMemcpyAsync(s.d_pix, s.h_pix, nframes * np * 2, hipMemcpyHostToDevice, s.stream));
+  }
   HIPOK(c, fpvhip::launch_predict(c->g, s.d_pix, nframes,
                                   with_delta ? c->d_dhigh : nullptr,
                                   with_delta ? c->d_dlow : nullptr, s.ws, s.d_high,
@@ -302,8 +340,22 @@ uint8_t* fpvhip_stage_plane(fpvhip_ctx* c, uint32_t slot, uint32_t k, int which)
   return (which ? s.h_low : s.h_high) + (size_t)k * c->g.npix;
 }
 
-int fpvhip_inverse_submit(fpvhip_ctx* c, uint32_t slot, uint32_t nframes,
-                          const uint8_t* flags) {
+static int inverse_submit_impl(fpvhip_ctx* c, uint32_t slot, uint32_t nframes,
+                               const uint8_t* flags, bool to_planes);
+
+int fpvhip_inverse_submit(fpvhip_ctx* c, uint32_t slot, uint32_t nframes, const uint8_t* flags) {
+  return inverse_submit_impl(c, slot, nframes, flags, false);
+}
+
+int fpvhip_inverse_planes_submit(fpvhip_ctx* c, uint32_t slot, uint32_t nframes,
+                                 const uint8_t* flags) {
+  if (c && ((uint64_t)c->g.npix * nframes >= (1ull << 32) || (c->g.npix & 3)))
+    return fail(c, "batch too large / odd size for plane output");
+  return inverse_submit_impl(c, slot, nframes, flags, true);
+}
+
+static int inverse_submit_impl(fpvhip_ctx* c, uint32_t slot, uint32_t nframes,
+                               const uint8_t* flags, bool to_planes) {
   if (check_slot(c, slot)) return -1;
   if (nframes == 0 || nframes > c->max_batch || !flags) return fail(c, "bad arguments");
   Slot& s = c->slots[slot];
@@ -323,7 +375,13 @@ int fpvhip_inverse_submit(fpvhip_ctx* c, uint32_t slot, uint32_t nframes,
                                   c->have_delta ? c->d_dhigh : nullptr,
                                   c->have_delta ? c->d_dlow : nullptr, s.d_flags,
                                   nframes, s.d_pix, s.stream));
-  HIPOK(c, hipMemcpyAsync(s.h_pix, s.d_pix, nframes * np * 2, hipMemcpyDeviceToHost, s.stream));
+  if (to_planes) {  // (pixel >> 8, pixel & 0xff) back into the plane staging buffers
+    HIPOK(c, fpvhip::launch_split_planes(s.d_pix, s.d_high, s.d_low, nframes * np, s.stream));
+    HIPOK(c, hipMemcpyAsync(s.h_high, s.d_high, nframes * np, hipMemcpyDeviceToHost, s.stream));
+    HIPOK(c, hipMemcpyAsync(s.h_low, s.d_low, nframes * np, hipMemcpyDeviceToHost, s.stream));
+  } else {
+    HIPOK(c, hipMemcpyAsync(s.h_pix, s.d_pix, nframes * np * 2, hipMemcpyDeviceToHost, s.stream));
+  }
   HIPOK(c, hipEventRecord(s.done, s.stream));
   s.pending = nframes;
   return 0;

@@ -70,6 +70,25 @@ void ReleaseEncoderCtx(fpvhip_ctx* ctx) {
   for (fpvhip_ctx* c : drop) fpvhip_destroy(c);
 }
 
+fpvhip_ctx* AcquireDecoderCtx(int device, uint32_t xs, uint32_t ys) {
+  {
+    std::lock_guard<std::mutex> l(g_pool_m);
+    for (auto& e : g_pool) {
+      if (!e.in_use && e.device == device && e.xs == xs && e.ys == ys && e.shift == -1) {
+        e.in_use = true;
+        return e.ctx;
+      }
+    }
+  }
+  fpvhip_ctx* c = fpvhip_create_decoder(device, xs, ys, 1, 1);
+  if (!c) return nullptr;
+  std::lock_guard<std::mutex> l(g_pool_m);
+  g_pool.push_back(PoolEntry{device, xs, ys, 1, 1, -1, false, true, c});
+  return c;
+}
+
+void ReleaseDecoderCtx(fpvhip_ctx* ctx) { ReleaseEncoderCtx(ctx); }
+
 // ------------------------------------------------------- inverse engine -----
 
 std::shared_ptr<InverseEngine> InverseEngine::Create(size_t xs, size_t ys, uint32_t batch,

@@ -43,6 +43,9 @@ void AppendCore(const uint8_t* high, const uint8_t* low, uint8_t flags, size_t n
 fpvhip_ctx* AcquireEncoderCtx(int device, uint32_t xs, uint32_t ys, int shift,
                               bool big_endian, uint32_t batch, uint32_t slots);
 void ReleaseEncoderCtx(fpvhip_ctx* ctx);
+// Same cache for small inverse contexts (batch 1, one slot) used by Frame::Uncompress.
+fpvhip_ctx* AcquireDecoderCtx(int device, uint32_t xs, uint32_t ys);
+void ReleaseDecoderCtx(fpvhip_ctx* ctx);
 
 // Inverse predictor front end shared by the two decoders: Brotli-decodes the
 // planes of an image chunk straight into a slot's pinned staging memory and

@@ -69,7 +69,13 @@ hipError_t launch_copy(const void* src, void* dst, size_t bytes, hipStream_t s);
 
 // Raw split of one frame into byte planes (delta frame set-up, cc:370-451).
 hipError_t launch_split(const Geom& g, const uint16_t* d_img, uint8_t* d_high,
-                        uint8_t* d_low, hipStream_t s);
+                        uint8_t* d_low, uint32_t* d_anylow, hipStream_t s);
+// high << 8 | low for npix_total pixels (multiple of 4); d_low may be null.
+hipError_t launch_interleave(const uint8_t* d_high, const uint8_t* d_low, uint16_t* d_img,
+                             size_t npix_total, hipStream_t s);
+// pixels -> (px >> 8, px & 0xff) planes for npix_total pixels (multiple of 4, < 2^32).
+hipError_t launch_split_planes(const uint16_t* d_img, uint8_t* d_high, uint8_t* d_low,
+                               size_t npix_total, hipStream_t s);
 // Decoded delta image -> byte planes (decoder side, cc:337-338).
 hipError_t launch_split_decoded(const Geom& g, const uint16_t* d_img,
                                 uint8_t* d_high, uint8_t* d_low, hipStream_t s);

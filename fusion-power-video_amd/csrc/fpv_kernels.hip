@@ -110,15 +110,37 @@ __global__ __launch_bounds__(kThreads) void k_copy(const uint4* __restrict__ src
 template <bool SWAP>
 __global__ __launch_bounds__(kThreads) void k_split(
     const uint16_t* __restrict__ img, uint8_t* __restrict__ high,
-    uint8_t* __restrict__ low, uint32_t npix, int S) {
+    uint8_t* __restrict__ low, uint32_t npix, int S, uint32_t* __restrict__ anylow) {
   uint32_t i = (blockIdx.x * kThreads + threadIdx.x) * 4;
-  if (i >= npix) return;  // npix is a multiple of 16
-  const uint2 v = *reinterpret_cast<const uint2*>(img + i);
-  uint32_t h4, l4;
-  split4<SWAP>(v.x, v.y, S, &h4, &l4);
-  if (S == 8) l4 = 0;
-  *reinterpret_cast<uint32_t*>(high + i) = h4;
-  *reinterpret_cast<uint32_t*>(low + i) = l4;
+  uint32_t l4 = 0;
+  if (i < npix) {  // npix is a multiple of 16
+    const uint2 v = *reinterpret_cast<const uint2*>(img + i);
+    uint32_t h4;
+    split4<SWAP>(v.x, v.y, S, &h4, &l4);
+    if (S == 8) l4 = 0;
+    *reinterpret_cast<uint32_t*>(high + i) = h4;
+    *reinterpret_cast<uint32_t*>(low + i) = l4;
+  }
+  if (anylow) {  // NO_LOW_BYTES of the Frame ctor (cc:447-449)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) l4 |= __shfl_xor(l4, off, 64);
+    if ((threadIdx.x & 63) == 0 && l4) atomicOr(anylow, l4);
+  }
+}
+
+// Byte planes -> uint16 pixels (high << 8 | low): lets frames that exist only
+// as planes (Frame API) go through the same forward kernels with shift 0.
+__global__ __launch_bounds__(kThreads) void k_interleave(
+    const uint8_t* __restrict__ high, const uint8_t* __restrict__ low,
+    uint16_t* __restrict__ img, size_t npix_total) {
+  const size_t i = ((size_t)blockIdx.x * kThreads + threadIdx.x) * 4;
+  if (i >= npix_total) return;
+  const uint32_t h4 = *reinterpret_cast<const uint32_t*>(high + i);
+  const uint32_t l4 = low ? *reinterpret_cast<const uint32_t*>(low + i) : 0u;
+  uint2 o;
+  o.x = __builtin_amdgcn_perm(h4, l4, 0x05010400u);
+  o.y = __builtin_amdgcn_perm(h4, l4, 0x07030602u);
+  *reinterpret_cast<uint2*>(img + i) = o;
 }
 
 __global__ __launch_bounds__(kThreads) void k_split_decoded(
@@ -1467,12 +1489,26 @@ hipError_t launch_copy(const void* src, void* dst, size_t bytes, hipStream_t s) 
 }
 
 hipError_t launch_split(const Geom& g, const uint16_t* d_img, uint8_t* d_high,
-                        uint8_t* d_low, hipStream_t s) {
+                        uint8_t* d_low, uint32_t* d_anylow, hipStream_t s) {
   dim3 grid((g.npix / 4 + kThreads - 1) / kThreads);
   if (g.swap)
-    k_split<true><<<grid, kThreads, 0, s>>>(d_img, d_high, d_low, g.npix, g.shift);
+    k_split<true><<<grid, kThreads, 0, s>>>(d_img, d_high, d_low, g.npix, g.shift, d_anylow);
   else
-    k_split<false><<<grid, kThreads, 0, s>>>(d_img, d_high, d_low, g.npix, g.shift);
+    k_split<false><<<grid, kThreads, 0, s>>>(d_img, d_high, d_low, g.npix, g.shift, d_anylow);
+  return hipGetLastError();
+}
+
+hipError_t launch_interleave(const uint8_t* d_high, const uint8_t* d_low, uint16_t* d_img,
+                             size_t npix_total, hipStream_t s) {
+  k_interleave<<<(unsigned)((npix_total / 4 + kThreads - 1) / kThreads), kThreads, 0, s>>>(
+      d_high, d_low, d_img, npix_total);
+  return hipGetLastError();
+}
+
+hipError_t launch_split_planes(const uint16_t* d_img, uint8_t* d_high, uint8_t* d_low,
+                               size_t npix_total, hipStream_t s) {
+  k_split_decoded<<<(unsigned)((npix_total / 4 + kThreads - 1) / kThreads), kThreads, 0, s>>>(
+      d_img, d_high, d_low, (uint32_t)npix_total);
   return hipGetLastError();
 }
 

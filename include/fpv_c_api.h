@@ -50,6 +50,19 @@ int fpvc_stream_info(const uint8_t *data, size_t size, size_t *xs, size_t *ys,
 void fpvc_unextract(const uint16_t *img, size_t xs, size_t ys, int shift,
                     int big_endian, uint8_t *out);
 
+
+/* fpvc::Frame (h:75-139) drivers; see csrc/fpv_frame_capi.inc for semantics. */
+size_t fpvc_frame_compress_full(const uint16_t *img, const uint16_t *delta_raw,
+                                size_t xs, size_t ys, int shift, int big_endian,
+                                uint8_t *out, size_t cap);
+uint64_t fpvc_frame_cycle(const uint16_t *img, const uint16_t *delta_raw, size_t xs,
+                          size_t ys, int shift, int big_endian, int parallel,
+                          uint8_t *pred_high, uint8_t *pred_low, uint8_t *pred_preview,
+                          uint8_t *info, uint8_t *rest_high, uint8_t *rest_low,
+                          uint8_t *rest_preview);
+size_t fpvc_frame8_compress_core(const uint8_t *img8, const uint8_t *delta8, size_t xs,
+                                 size_t ys, uint8_t *out, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

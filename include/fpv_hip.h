@@ -88,6 +88,14 @@ int fpvhip_set_delta_decoded(fpvhip_ctx *ctx, const uint16_t *delta_img);
 int fpvhip_set_delta_planes(fpvhip_ctx *ctx, const uint8_t *high,
                             const uint8_t *low);
 
+/*
+ * Frame ctor alone (cc:370-451): raw split of ONE frame into its byte planes,
+ * *no_low = 1 when every low byte is zero (NO_LOW_BYTES, cc:447-449).  Host
+ * pointers; synchronous; uses slot 0.  low may be NULL.
+ */
+int fpvhip_split_frame(fpvhip_ctx *ctx, const uint16_t *img, uint8_t *high,
+                       uint8_t *low, int *no_low);
+
 /* ---- forward predictor, host-staged (Encoder pipeline) ------------------ */
 
 /* Pinned host buffer for input frame k of `slot` (npix uint16). */
@@ -110,6 +118,15 @@ int fpvhip_predict_wait(fpvhip_ctx *ctx, uint32_t slot, const uint8_t **high,
                         const uint8_t **low, const uint8_t **preview,
                         const uint8_t **flags);
 
+/*
+ * Frame::Predict on a frame that exists only as RAW byte planes (Frame ctors 2
+ * and 3, h:105-107): the planes staged with fpvhip_stage_plane are the INPUT.
+ * Needs a context created with shift 0 / little endian.  Wait with
+ * fpvhip_predict_wait.
+ */
+int fpvhip_predict_planes_submit(fpvhip_ctx *ctx, uint32_t slot, uint32_t nframes,
+                                 int with_delta);
+
 /* ---- inverse predictor, host-staged (decoders) -------------------------- */
 
 /* Pinned host buffer for plane `which` (0 high, 1 low) of frame k of `slot`:
@@ -125,6 +142,13 @@ int fpvhip_inverse_submit(fpvhip_ctx *ctx, uint32_t slot, uint32_t nframes,
                           const uint8_t *flags);
 int fpvhip_inverse_wait(fpvhip_ctx *ctx, uint32_t slot,
                         const uint16_t **frames);
+/*
+ * Frame::Uncompress's predictor half (cc:612-641, 595-610): like inverse_submit,
+ * but the result comes back as byte planes in the plane staging buffers (wait
+ * with fpvhip_predict_wait; only high and low are meaningful).
+ */
+int fpvhip_inverse_planes_submit(fpvhip_ctx *ctx, uint32_t slot, uint32_t nframes,
+                                 const uint8_t *flags);
 
 /* ---- device-resident entry points (inputs already in HBM) --------------- */
 

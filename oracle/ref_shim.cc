@@ -117,4 +117,11 @@ void ref_unextract(const uint16_t* img, size_t xs, size_t ys, int shift,
   fpvc::UnextractFrame(img, xs, ys, shift, big_endian != 0, out);
 }
 
+// The Frame-API drivers: the same text the product compiles against its own
+// header (fusion-power-video_amd/csrc/fpv_frame_capi.inc), here compiled
+// against the UPSTREAM header and library.
+#define FPV_FN(name) ref_##name
+#include "fpv_frame_capi.inc"
+#undef FPV_FN
+
 }  // extern "C"

@@ -132,7 +132,28 @@ def main():
         "input_sha256": sha(p4k), "flags": [ref.predict(p4k[k], 4096, 4096, 0, False, p4k[0])[3] for k in range(2)],
         "fpv_sha256": sha(fpv), "fpv_size": int(fpv.size)}
     json.dump(man, open(os.path.join(HERE, "manifest.json"), "w"), indent=1)
+    frame_api_golden()
     print(json.dumps({k: v["fpv_size"] for k, v in man["workloads"].items()}))
+
+
+def frame_api_golden():
+    """Frame public API (h:75-139) through the reference: fixtures for
+    tests/test_frame_api.py."""
+    import ctypes
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from frame_api_driver import FrameApi, cases
+    api = FrameApi(ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", "libfpvref.so")), "ref_")
+    xs, ys, cs = cases(synth)
+    out = {}
+    for name, img, delta, shift, be in cs:
+        out[name + "/full"] = api.compress_full(img, delta, xs, ys, shift, be)
+        if delta is not None:
+            for k, v in api.cycle(img, delta, xs, ys, shift, be).items():
+                out[name + "/" + k] = v
+    fr = synth.plasma_frames(2, xs, ys, bits=12, seed=3)
+    out["frame8/core"] = api.compress8_core((fr[1] >> 4).astype(np.uint8), (fr[0] >> 4).astype(np.uint8), xs, ys)
+    np.savez_compressed(os.path.join(HERE, "frame_api.npz"), **out)
+    print("frame_api.npz:", len(out), "arrays")
 
 
 def ref_shifted(frames, shift, be):

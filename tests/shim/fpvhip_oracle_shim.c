@@ -103,9 +103,18 @@ int fpvhip_set_delta_decoded(fpvhip_ctx *c, const uint16_t *d) {
   return 0;
 }
 int fpvhip_set_delta_planes(fpvhip_ctx *c, const uint8_t *h, const uint8_t *l) {
+  size_t i;
   memcpy(c->dhigh, h, c->npix);
   if (l) memcpy(c->dlow, l, c->npix); else memset(c->dlow, 0, c->npix);
+  for (i = 0; i < c->npix; i++) c->d16[i] = (uint16_t)((c->dhigh[i] << 8) | c->dlow[i]);
   c->have_delta = 1;
+  return 0;
+}
+
+int fpvhip_split_frame(fpvhip_ctx *c, const uint16_t *img, uint8_t *high, uint8_t *low, int *no_low) {
+  uint8_t *tmp = low ? low : (uint8_t *)malloc(c->npix);
+  *no_low = fpvo_split(img, c->npix, c->shift, c->be, high, tmp);
+  if (!low) free(tmp);
   return 0;
 }
 
@@ -143,6 +152,14 @@ int fpvhip_predict_wait(fpvhip_ctx *c, uint32_t slot, const uint8_t **high,
   return 0;
 }
 
+int fpvhip_predict_planes_submit(fpvhip_ctx *c, uint32_t slot, uint32_t n, int with_delta) {
+  slot_t *s = &c->slots[slot];
+  size_t i;
+  if (c->shift != 0 || c->be) { snprintf(c->err, sizeof c->err, "planes input needs shift 0"); return -1; }
+  for (i = 0; i < (size_t)n * c->npix; i++) s->pix[i] = (uint16_t)((s->high[i] << 8) | s->low[i]);
+  return fpvhip_predict_submit(c, slot, n, with_delta);
+}
+
 uint8_t *fpvhip_stage_plane(fpvhip_ctx *c, uint32_t slot, uint32_t k, int which) {
   slot_t *s = &c->slots[slot];
   return (which ? s->low : s->high) + (size_t)k * c->npix;
@@ -163,6 +180,25 @@ int fpvhip_inverse_submit(fpvhip_ctx *c, uint32_t slot, uint32_t n, const uint8_
   s->pending = n;
   return 0;
 }
+int fpvhip_inverse_planes_submit(fpvhip_ctx *c, uint32_t slot, uint32_t n, const uint8_t *flags) {
+  slot_t *s = &c->slots[slot];
+  uint32_t k;
+  size_t i;
+  for (k = 0; k < n; k++) {
+    uint8_t *h = s->high + (size_t)k * c->npix, *l = s->low + (size_t)k * c->npix;
+    if ((flags[k] & 1) && !c->have_delta) { snprintf(c->err, sizeof c->err, "delta frame not given"); return -1; }
+    if (flags[k] & 2) fpvo_cg_inverse(h, c->xs, c->npix);
+    if (flags[k] & 1)
+      for (i = 0; i < c->npix; i++) {
+        h[i] = (uint8_t)(h[i] + c->dhigh[i]);
+        l[i] = (uint8_t)(((flags[k] & 4) ? 0 : l[i]) + c->dlow[i]);
+      }
+    else if (flags[k] & 4) memset(l, 0, c->npix);
+  }
+  s->pending = n;
+  return 0;
+}
+
 int fpvhip_inverse_wait(fpvhip_ctx *c, uint32_t slot, const uint16_t **frames) {
   slot_t *s = &c->slots[slot];
   if (!s->pending) { snprintf(c->err, sizeof c->err, "nothing in flight"); return -1; }

@@ -77,7 +77,7 @@ def hip_lib():
     """The C-ABI library (include/fpv_hip.h).  Raises when it is not built."""
     global _hip
     if _hip is None:
-        path = os.path.join(LIBDIR, "libfpvhip.so")
+        path = os.environ.get("FPV_HIP_LIB") or os.path.join(LIBDIR, "libfpvhip.so")  # override: diagnostic builds
         if not os.path.exists(path):
             raise FpvError(f"{path} is missing: run `make product` (no CPU fallback exists)")
         _hip = ctypes.CDLL(path)

@@ -469,6 +469,13 @@ double fpvhip_time_predict_device(fpvhip_ctx* c, const void* d_frames,
   return ms;
 }
 
+int fpvhip_debug_counters(fpvhip_ctx* c, uint32_t* out, uint32_t n) {
+  if (!c || !out || n > 64 || !c->g.fwd_ok) return fail(c, "bad arguments");
+  HIPOK(c, hipDeviceSynchronize());
+  HIPOK(c, hipMemcpy(out, c->ws.counters, n * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
 double fpvhip_time_copy_device(void* d_dst, const void* d_src, size_t bytes, void* stream,
                                int iters) {
   hipStream_t st = static_cast<hipStream_t>(stream);

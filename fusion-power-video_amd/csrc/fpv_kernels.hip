@@ -558,7 +558,24 @@ struct Pre {  // prefetch registers of one step
   uint4 a, b, dh, dl;
 };
 
+#ifdef FPV_STAMPS
+#define FPV_STAMP(k)                                                                      \
+  do {                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+    unsigned long long t_;                                                                \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");           \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+    c.seg[k] += t_ - c.tlast;                                                             \
+    c.tlast = t_;                                                                         \
+  } while (0)
+#else
+#define FPV_STAMP(k)
+#endif
+
 struct StreamCtx {
+#ifdef FPV_STAMPS
+  unsigned long long seg[6], tlast;
+#endif
   // constant per kernel
   uint32_t lane, xs, pw, ring_mask, ring_base, nacc, shift;
   uint8_t* ring;
@@ -644,12 +661,17 @@ template <bool SWAP, bool FAST, bool DELTA, bool LOW>
 __device__ __forceinline__ void stream_step(StreamCtx& c, uint32_t it, const Pre& p) {
   const uint32_t o = it * kStep + c.lane * 16;
   const int S = (int)c.shift;
+  FPV_STAMP(0);  // loop overhead + prefetch issue of the previous step
   if (FAST || o < c.npx) {
     uint4 h, l;
     split4<SWAP>(p.a.x, p.a.y, S, &h.x, &l.x);
     split4<SWAP>(p.a.z, p.a.w, S, &h.y, &l.y);
     split4<SWAP>(p.b.x, p.b.y, S, &h.z, &l.z);
     split4<SWAP>(p.b.z, p.b.w, S, &h.w, &l.w);
+#ifdef FPV_STAMPS
+    asm volatile("" ::"v"(h.x), "v"(h.w), "v"(l.x), "v"(l.w));
+#endif
+    FPV_STAMP(1);  // wait for the pixel loads + split
     // preview: 4-pixel sums of the RAW high bytes into the group accumulators (cc:500-509)
     {
       const uint32_t q[4] = {__builtin_amdgcn_sad_u8(h.x, 0, 0), __builtin_amdgcn_sad_u8(h.y, 0, 0),
@@ -678,6 +700,7 @@ __device__ __forceinline__ void stream_step(StreamCtx& c, uint32_t it, const Pre
       c.m15 += kStep % 15u;
       if (c.m15 >= 15u) c.m15 -= 15u;
     }
+    FPV_STAMP(2);  // preview adds + delta-histogram sample
     if (DELTA) {  // cc:534-537
       h.x = sub4(h.x, p.dh.x); h.y = sub4(h.y, p.dh.y);
       h.z = sub4(h.z, p.dh.z); h.w = sub4(h.w, p.dh.w);
@@ -691,6 +714,7 @@ __device__ __forceinline__ void stream_step(StreamCtx& c, uint32_t it, const Pre
     *reinterpret_cast<uint4*>(c.ring + a0) = h;
     if (!c.use_cg) st_stream(c.high_f + c.s + o, h);
     __builtin_amdgcn_wave_barrier();  // the reads below see the whole wave's ring writes
+    FPV_STAMP(3);  // delta + low store + ring write
     if (c.use_cg) {  // cc:566-571
       uint32_t n0, c0;
       uint4 nv;
@@ -727,6 +751,7 @@ __device__ __forceinline__ void stream_step(StreamCtx& c, uint32_t it, const Pre
       }
       st_stream(c.high_f + c.s + o, r);
     }
+    FPV_STAMP(4);  // ring reads + clamped gradient + high store
     {  // cc:554-562: the CG heuristic's sample at i = xs + 1 + 31 k, if one falls in this segment
       const uint32_t j1 = c.q31 < 0 ? (uint32_t)(-c.q31) : (c.q31 ? 31u - (uint32_t)c.q31 : 0u);
       if (j1 < 16) {
@@ -753,12 +778,13 @@ __device__ __forceinline__ void stream_step(StreamCtx& c, uint32_t it, const Pre
   // preview groups completed by this step (wave-uniform)
   const uint32_t end = min((it + 1) * kStep, c.npx);
   stream_preview_flush(c, end / (4 * c.xs));
+  FPV_STAMP(5);  // CG sample + bookkeeping + preview flush
 }
 
 // Kernel arguments kept small on purpose: everything else is derived.
 struct StreamArgs {
   uint32_t xs, ys, npix, pw, npv;
-  uint32_t strip_rows, strips, ring_fwd, ring_base, nacc, shift, nframes;
+  uint32_t strip_rows, strips, ring_fwd, ring_base, nacc, shift, nframes, strip_major;
 };
 
 template <bool SWAP, bool FAST, bool DELTA, bool LOW>
@@ -781,6 +807,10 @@ __global__ __launch_bounds__(64, 4) void k_stream(
   c.use_delta = DELTA;
   c.use_cg = spec & 2;
   c.dh = dhigh; c.dl = dlow;
+#ifdef FPV_STAMPS
+  for (int k = 0; k < 6; k++) c.seg[k] = 0;
+  c.tlast = __builtin_amdgcn_s_memtime();
+#endif
   for (uint32_t k = c.lane; k < g.nacc * g.pw; k += 64) c.acc[k] = 0;
   const uint32_t row_l = (c.lane * 16) / g.xs, col_l = (c.lane * 16) % g.xs;
 
@@ -789,8 +819,24 @@ __global__ __launch_bounds__(64, 4) void k_stream(
     uint32_t task = 0;
     if (c.lane == 0) task = atomicAdd(&counters[6], 1u);
     task = __builtin_amdgcn_readfirstlane(task);
-    if (task >= ntasks) break;
-    const uint32_t frame = task / g.strips, strip = task - frame * g.strips;
+    if (task >= ntasks) {
+#ifdef FPV_STAMPS
+      if (c.lane == 0)  // stamps leave through a buffer nothing else reads (counters[16..27])
+        for (int k = 0; k < 6; k++)
+          atomicAdd(reinterpret_cast<unsigned long long*>(counters + 16) + k, c.seg[k]);
+#endif
+      break;
+    }
+    // Strip-major order: waves resident at the same time work on the SAME strip of
+    // different frames, so the strip's delta bytes are shared through L1/L2.
+    uint32_t frame, strip;
+    if (g.strip_major) {
+      strip = task / g.nframes;
+      frame = task - strip * g.nframes;
+    } else {
+      frame = task / g.strips;
+      strip = task - frame * g.strips;
+    }
     const uint32_t row0 = strip * g.strip_rows;
     const uint32_t rows = min(g.strip_rows, g.ys - row0);
     const size_t fbase = (size_t)frame * g.npix;
@@ -1548,6 +1594,8 @@ static hipError_t predict_impl(const Geom& g, const uint16_t* d_frames,
     a.xs = g.xs; a.ys = g.ys; a.npix = g.npix; a.pw = g.pw; a.npv = g.npv;
     a.strip_rows = g.strip_rows; a.strips = g.strips; a.ring_fwd = g.ring_fwd;
     a.ring_base = g.ring_base; a.nacc = g.nacc; a.shift = (uint32_t)g.shift; a.nframes = nframes;
+    static const int strip_major = getenv("FPV_STRIP_MAJOR") ? atoi(getenv("FPV_STRIP_MAJOR")) : 1;
+    a.strip_major = (uint32_t)strip_major;
     // FAST needs every step of every strip to be full and a segment never to
     // straddle image rows.  Both delta variants are launched; the one that does
     // not match the speculation byte (device memory) exits at once.

@@ -184,6 +184,9 @@ double fpvhip_time_predict_device(fpvhip_ctx *ctx, const void *d_frames,
                                   void *d_high, void *d_low, void *d_preview,
                                   void *d_flags, void *stream, int iters,
                                   double *kernel_ms);
+/* Diagnostics: the first n (<= 64) dwords of the device-entry-point workspace's
+ * counter block after the last predict_device (list sizes, votes, task counter). */
+int fpvhip_debug_counters(fpvhip_ctx *ctx, uint32_t *out, uint32_t n);
 /* Bench only: `iters` plain 16-B-per-lane device copies of `bytes` bytes on
  * `stream`; returns elapsed ms.  The measured HBM ceiling kernels are compared with. */
 double fpvhip_time_copy_device(void *d_dst, const void *d_src, size_t bytes,

@@ -37,6 +37,7 @@ struct Slot {
   void* d_ws = nullptr;
   FwdWorkspace ws{};
   uint32_t pending = 0;  // frames of the batch in flight
+  bool ready = false;    // buffers allocated (slots after the first are allocated on first use)
 };
 
 }  // namespace
@@ -98,6 +99,7 @@ int alloc_slot(fpvhip_ctx* c, Slot* s) {
     fpvhip::carve_fwd_workspace(c->g, c->max_batch, s->d_ws, &s->ws);
     HIPOK(c, fpvhip::init_fwd_workspace(s->ws, s->stream));
   }
+  s->ready = true;
   return 0;
 }
 
@@ -112,9 +114,16 @@ void free_slot(Slot* s) {
   *s = Slot();
 }
 
+// Pinned allocations are slow (tens of ms per slot): only slot 0 is allocated
+// by create; the others when they are first touched, which in the encoder
+// pipeline overlaps with the GPU and Brotli work of the batches before.
 int check_slot(fpvhip_ctx* c, uint32_t slot) {
   if (!c) return fail(nullptr, "null context");
   if (slot >= c->slots.size()) return fail(c, "slot %u out of range", slot);
+  if (!c->slots[slot].ready) {
+    if (hipSetDevice(c->device) != hipSuccess) return fail(c, "hipSetDevice failed");
+    if (alloc_slot(c, &c->slots[slot])) return -1;
+  }
   return 0;
 }
 
@@ -171,8 +180,7 @@ static fpvhip_ctx* create_impl(int device, const Geom& g, uint32_t max_batch,
     }
     for (auto& e : c->ev) HIPOK(c, hipEventCreate(&e));
     c->slots.resize(slots);
-    for (auto& s : c->slots)
-      if (alloc_slot(c, &s)) return -1;
+    if (slots && alloc_slot(c, &c->slots[0])) return -1;
     return 0;
   };
   if (setup()) {
@@ -467,6 +475,20 @@ double fpvhip_time_predict_device(fpvhip_ctx* c, const void* d_frames,
     }
   }
   return ms;
+}
+
+int fpvhip_warmup(int device) {
+  int n = fpvhip_device_count();
+  if (n <= 0) return -1;
+  if (device < 0 || device >= n) return fail(nullptr, "device %d out of range", device);
+  HIPOK(nullptr, hipSetDevice(device));
+  HIPOK(nullptr, hipFree(nullptr));  // creates the primary context
+  void* p = nullptr;
+  HIPOK(nullptr, hipMalloc(&p, 4096));
+  HIPOK(nullptr, fpvhip::launch_copy(p, p, 0, nullptr));  // loads the code object
+  HIPOK(nullptr, hipDeviceSynchronize());
+  HIPOK(nullptr, hipFree(p));
+  return 0;
 }
 
 int fpvhip_debug_counters(fpvhip_ctx* c, uint32_t* out, uint32_t n) {

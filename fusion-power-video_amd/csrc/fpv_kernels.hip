@@ -918,6 +918,7 @@ __global__ __launch_bounds__(kThreads) void k_decide_spec(
   const uint32_t nparts = g.stream ? g.strips : g.tiles;
   const uint16_t* ph = partials + (size_t)frame * nparts * (kHistFused * 256);
   uint32_t v[kHistFused] = {0, 0, 0};
+#pragma unroll 8
   for (uint32_t t = 0; t < nparts; t++) {
 #pragma unroll
     for (int h = 0; h < kHistFused; h++) v[h] += ph[(t * kHistFused + h) * 256 + tid];
@@ -1068,6 +1069,8 @@ __global__ __launch_bounds__(kThreads) void k_apply_list(
 
 // Preview clamped gradient (cc:575-586), final flags byte (cc:447-449) and the
 // speculation for the next batch (majority of this batch's decisions).
+// WIDE: pw % 16 == 0 -> 16 preview pixels per thread with the packed median.
+template <bool WIDE>
 __global__ __launch_bounds__(kThreads) void k_finish(
     const uint8_t* __restrict__ pv_raw, const uint8_t* __restrict__ decision,
     const uint32_t* __restrict__ anylow, const uint32_t* __restrict__ counters,
@@ -1077,9 +1080,25 @@ __global__ __launch_bounds__(kThreads) void k_finish(
   const uint32_t dec = decision[frame];
   const uint8_t* in = pv_raw + (size_t)frame * g.npv;
   uint8_t* out = preview + (size_t)frame * g.npv;
-  const uint32_t i = (blockIdx.x * kThreads + threadIdx.x) * 4;
+  constexpr uint32_t kPer = WIDE ? 16 : 4;
+  const uint32_t i = (blockIdx.x * kThreads + threadIdx.x) * kPer;
   if (i < g.npv) {
-    if ((g.pw & 3) == 0) {  // npv and pw multiples of 4: dword path
+    if (WIDE) {
+      const uint4 c4 = *reinterpret_cast<const uint4*>(in + i);
+      uint4 r4 = c4;
+      if ((dec & 2) && i >= g.pw) {  // rows >= 1; row 0 and pixel pw are literals
+        const uint4 n4 = *reinterpret_cast<const uint4*>(in + i - g.pw);
+        // west / north-west of the first pixel: the dwords in front of the two segments
+        uint32_t xo_prev = __builtin_amdgcn_perm(0, *reinterpret_cast<const uint32_t*>(in + i - 4), 0x0c030c01u);
+        uint32_t no_prev = i > g.pw ? __builtin_amdgcn_perm(0, *reinterpret_cast<const uint32_t*>(in + i - g.pw - 4), 0x0c030c01u) : 0u;
+        r4.x = cg_res4(c4.x, n4.x, &xo_prev, &no_prev);
+        r4.y = cg_res4(c4.y, n4.y, &xo_prev, &no_prev);
+        r4.z = cg_res4(c4.z, n4.z, &xo_prev, &no_prev);
+        r4.w = cg_res4(c4.w, n4.w, &xo_prev, &no_prev);
+        if (i == g.pw) r4.x = (r4.x & 0xffffff00u) | (c4.x & 0xffu);  // pixel pw itself is a literal
+      }
+      *reinterpret_cast<uint4*>(out + i) = r4;
+    } else if ((g.pw & 3) == 0) {  // npv and pw multiples of 4: dword path
       const uint32_t c4 = *reinterpret_cast<const uint32_t*>(in + i);
       uint32_t r4 = c4;
       if ((dec & 2) && i + 3 >= g.pw + 1) {
@@ -1640,8 +1659,12 @@ static hipError_t predict_impl(const Geom& g, const uint16_t* d_frames,
       d_frames, d_dhigh, d_dlow, ws.decision, ws.counters, ws.list_b, d_high, d_low, ws.pv_raw,
       ws.anylow, g);
   if (ev) hipEventRecord(ev[3], s);
-  k_finish<<<dim3((g.npv / 4 + kThreads) / kThreads, nframes), kThreads, 0, s>>>(
-      ws.pv_raw, ws.decision, ws.anylow, ws.counters, d_preview, d_flags, ws.spec, g);
+  if ((g.pw & 15) == 0)
+    k_finish<true><<<dim3((g.npv / 16 + kThreads - 1) / kThreads, nframes), kThreads, 0, s>>>(
+        ws.pv_raw, ws.decision, ws.anylow, ws.counters, d_preview, d_flags, ws.spec, g);
+  else
+    k_finish<false><<<dim3((g.npv / 4 + kThreads) / kThreads, nframes), kThreads, 0, s>>>(
+        ws.pv_raw, ws.decision, ws.anylow, ws.counters, d_preview, d_flags, ws.spec, g);
   if (ev) hipEventRecord(ev[4], s);
   return hipGetLastError();
 }

@@ -40,6 +40,9 @@ typedef struct fpvhip_ctx fpvhip_ctx;
 int fpvhip_abi_version(void);
 /* Number of visible HIP devices, or < 0 when the runtime cannot be used. */
 int fpvhip_device_count(void);
+/* Initialises the HIP runtime, the device's context and the kernels' code
+ * object ahead of the first create (100s of ms once per process). */
+int fpvhip_warmup(int device);
 /* Last error text of ctx, or of the calling thread when ctx == NULL. */
 const char *fpvhip_last_error(const fpvhip_ctx *ctx);
 

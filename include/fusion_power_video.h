@@ -169,10 +169,10 @@ class Encoder {
   // Emits header + compressed delta frame through `callback` before returning.
   void Init(const uint16_t* delta_frame, size_t xsize, size_t ysize,
             Callback callback, void* payload);
-  // Queues one frame.  `img` is copied into pinned staging memory before the
-  // call returns (the upstream contract -- keep it alive until its callback --
-  // is therefore always sufficient).  Blocks while MaxQueued() frames are in
-  // flight.
+  // Queues one frame.  As upstream: `img` must stay valid until this frame's
+  // callback has run (worker threads copy it into pinned staging memory), so
+  // the caller needs MaxQueued() buffers.  Blocks while MaxQueued() frames are
+  // in flight.  With num_threads == 0 the frame is consumed before the call returns.
   void CompressFrame(const uint16_t* img, Callback callback, void* payload);
   // Drains everything, then emits the frame index.  Idempotent.
   void Finish(Callback callback, void* payload);

@@ -50,8 +50,22 @@ int main(int argc, char** argv) {
   if (n == 0) { fprintf(stderr, "no complete frame in %s\n", argv[1]); return 1; }
   const uint16_t* px = reinterpret_cast<const uint16_t*>(raw.data());
 
+  if (getenv("FPV_BENCH_NOCOPY")) {  // pipeline limit: the callback only counts bytes
+    size_t total = 0;
+    const double t0 = Now();
+    {
+      fpvc::Encoder enc(threads, shift, be);
+      auto count = [](const uint8_t*, size_t sz, void* p) { *static_cast<size_t*>(p) += sz; };
+      enc.Init(px, xs, ys, count, &total);
+      for (size_t i = 0; i < n; i++) enc.CompressFrame(px + i * npix, count, &total);
+      enc.Finish(count, &total);
+    }
+    const double dt = Now() - t0;
+    fprintf(stderr, "encode (count-only callback): %zu frames in %.3f s = %.1f fps, %zu bytes, %zu threads\n",
+            n, dt, n / dt, total, threads);
+  }
   Collect out;
-  out.bytes.reserve(n * fbytes / 2);
+  out.bytes.reserve(n * fbytes * 3 / 5);
   for (int rep = 0; rep < 2; rep++) {  // rep 0 warms contexts / pinned memory
     out.bytes.clear();
     const double t0 = Now();

@@ -29,11 +29,14 @@ int main(int argc, char** argv) {
     return 2;
   }
   fpvc::Encoder enc(threads, shift, be);
-  // CompressFrame copies the pixels before returning, one buffer is enough.
-  std::vector<uint16_t> frame(xs * ys);
+  // A frame must stay valid until its callback: rotate through MaxQueued() buffers
+  // (CompressFrame blocks while that many frames are in flight).
+  std::vector<std::vector<uint16_t>> ring(enc.MaxQueued(), std::vector<uint16_t>(xs * ys));
   bool first = true;
   size_t n = 0;
-  while (fread(frame.data(), 2, frame.size(), stdin) == frame.size()) {
+  for (;;) {
+    std::vector<uint16_t>& frame = ring[n % ring.size()];
+    if (fread(frame.data(), 2, frame.size(), stdin) != frame.size()) break;
     if (first) {
       enc.Init(frame.data(), xs, ys, ToStdout, nullptr);
       first = false;

@@ -33,6 +33,15 @@ ALG_BYTES_PER_FRAME = 2 * NPIX + NPIX + NPIX + NPIX // 16   # 4.062
 HBM_PEAK_GBPS = 8000.0                                      # MI355X_MICROARCH.md: 8 TB/s spec
 
 
+def cpu_quota():
+    """CPUs this container may actually use (cgroup v2 quota), or None."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if q == "max" else round(int(q) / int(per), 2)
+    except Exception:
+        return None
+
+
 def cpu_baseline(frames, seconds=12.0):
     """Time the CPU checker on this host's cores over a bounded sample of the
     same workload: Frame ctor + Frame::Predict per frame, single thread."""
@@ -50,7 +59,7 @@ def cpu_baseline(frames, seconds=12.0):
             break
     return {"value": round(n / el, 2), "unit": "frames/s", "cores": 1, "kind": kind,
             "sample": f"{n} frames of the same 1280x800 plasma workload, Frame ctor + Predict, 1 thread, {el:.1f} s",
-            "host_cpus": os.cpu_count()}
+            "host_cpus": os.cpu_count(), "host_cpu_quota": cpu_quota()}
 
 
 def main():

@@ -911,8 +911,7 @@ __device__ __forceinline__ uint64_t entropy_bins(uint32_t v, uint32_t* scratch) 
 __global__ __launch_bounds__(kThreads) void k_decide_spec(
     const uint16_t* __restrict__ partials, const uint8_t* __restrict__ spec_ptr,
     uint8_t* __restrict__ decision, uint32_t* __restrict__ counters,
-    uint32_t* __restrict__ list_a, uint32_t* __restrict__ list_b, Geom g, int with_delta,
-    int force) {
+    uint32_t* __restrict__ list_a, uint32_t* __restrict__ list_b, Geom g, int with_delta) {
   __shared__ uint32_t scratch[4];
   const uint32_t frame = blockIdx.x, tid = threadIdx.x;
   const uint32_t nparts = g.stream ? g.strips : g.tiles;
@@ -925,8 +924,7 @@ __global__ __launch_bounds__(kThreads) void k_decide_spec(
   }
   const uint32_t spec = *spec_ptr & (with_delta ? 3u : 2u);
   // cc:533: E(countd) < E(counta); countd has everything in bin 0, E(countd) == 0
-  bool use_delta = with_delta && entropy_bins(v[0], scratch) > 0;
-  if (force >= 0) use_delta = with_delta && (force & 1);  // ablation knob, never set in production
+  const bool use_delta = with_delta && entropy_bins(v[0], scratch) > 0;
   if (use_delta != (bool)(spec & 1)) {
     if (tid == 0) {
       decision[frame] = 0xff;
@@ -936,8 +934,7 @@ __global__ __launch_bounds__(kThreads) void k_decide_spec(
   }
   const uint64_t ea = entropy_bins(v[1], scratch);
   const uint64_t eb = entropy_bins(v[2], scratch);
-  bool use_cg = eb < ea;  // cc:564
-  if (force >= 0) use_cg = force & 2;
+  const bool use_cg = eb < ea;  // cc:564
   if (tid == 0) {
     const uint32_t dec = (use_delta ? 1u : 0u) | (use_cg ? 2u : 0u);
     decision[frame] = (uint8_t)dec;
@@ -1000,19 +997,17 @@ __global__ __launch_bounds__(kThreads) void k_stats_list(
 __global__ __launch_bounds__(kThreads) void k_decide_list(
     const uint32_t* __restrict__ hists, uint8_t* __restrict__ decision,
     uint32_t* __restrict__ counters, const uint32_t* __restrict__ list_a,
-    uint32_t* __restrict__ list_b, int with_delta, int force) {
+    uint32_t* __restrict__ list_b, int with_delta) {
   __shared__ uint32_t scratch[4];
   const uint32_t na = counters[0];
   for (uint32_t w = blockIdx.x; w < na; w += gridDim.x) {
     const uint32_t frame = list_a[w];
     const uint32_t* gh = hists + (size_t)frame * kNumHists * 256;
-    bool use_delta = with_delta && entropy_bins(gh[threadIdx.x], scratch) > 0;
-    if (force >= 0) use_delta = with_delta && (force & 1);
+    const bool use_delta = with_delta && entropy_bins(gh[threadIdx.x], scratch) > 0;
     const uint32_t* ha = gh + (use_delta ? 3 : 1) * 256;
     const uint64_t ea = entropy_bins(ha[threadIdx.x], scratch);
     const uint64_t eb = entropy_bins(ha[256 + threadIdx.x], scratch);
-    bool use_cg = eb < ea;
-    if (force >= 0) use_cg = force & 2;
+    const bool use_cg = eb < ea;
     if (threadIdx.x == 0) {
       const uint32_t dec = (use_delta ? 1u : 0u) | (use_cg ? 2u : 0u);
       decision[frame] = (uint8_t)dec;
@@ -1592,7 +1587,6 @@ static hipError_t predict_impl(const Geom& g, const uint16_t* d_frames,
                                uint8_t* d_preview, uint8_t* d_flags,
                                hipStream_t s, hipEvent_t* ev) {
   const int with_delta = d_dhigh != nullptr;
-  static const int force = getenv("FPV_DEBUG_FORCE") ? atoi(getenv("FPV_DEBUG_FORCE")) : -1;
   hipError_t e;
   if ((e = hipMemsetAsync(ws.counters, 0, ws.zero_fixed + (size_t)nframes * kNumHists * 256 * 4, s)) !=
       hipSuccess)
@@ -1648,13 +1642,13 @@ static hipError_t predict_impl(const Geom& g, const uint16_t* d_frames,
   }
   if (ev) hipEventRecord(ev[1], s);
   k_decide_spec<<<nframes, kThreads, 0, s>>>(ws.partials, ws.spec, ws.decision, ws.counters,
-                                            ws.list_a, ws.list_b, g, with_delta, force);
+                                            ws.list_a, ws.list_b, g, with_delta);
   if (ev) hipEventRecord(ev[2], s);
   // exact redo of mis-speculated frames; all three exit at once when the lists are empty
   k_stats_list<SWAP><<<kListGrid, kThreads, 0, s>>>(d_frames, d_dhigh, ws.counters, ws.list_a,
                                                    ws.hists, g, with_delta);
   k_decide_list<<<kListGrid / 4, kThreads, 0, s>>>(ws.hists, ws.decision, ws.counters, ws.list_a,
-                                                  ws.list_b, with_delta, force);
+                                                  ws.list_b, with_delta);
   k_apply_list<SWAP><<<kListGrid, kThreads, g.lds_bytes, s>>>(
       d_frames, d_dhigh, d_dlow, ws.decision, ws.counters, ws.list_b, d_high, d_low, ws.pv_raw,
       ws.anylow, g);

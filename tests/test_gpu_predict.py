@@ -85,3 +85,25 @@ def test_partial_batches_reuse_workspace(fpv, synth, oracle):
             assert np.array_equal(low[k].cpu().numpy(), el)
             assert np.array_equal(pv[k].cpu().numpy(), ep)
     p.close()
+
+
+@pytest.mark.parametrize("env", [{"FPV_STREAM": "0"}, {"FPV_STREAM": "0", "FPV_CACHE_DELTA": "1", "FPV_XCD_MAP": "1"},
+                                 {"FPV_STRIP_ROWS": "4"}, {"FPV_STRIP_ROWS": "12", "FPV_WAVES_PER_CU": "2"},
+                                 {"FPV_INVERSE_SLOW": "1"}])
+def test_alternate_kernel_paths(fpv, synth, oracle, env):
+    """The tile-based fused kernel (used for very wide frames), odd strip sizes
+    (partial last steps, non-FAST streaming variant) and the generic inverse
+    kernel must give the same bits as the default paths."""
+    import os
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        fr = np.concatenate([synth.plasma_frames(3, 320, 200, bits=12, seed=5),
+                             (synth.noise_frames(3, 320, 200, seed=6) >> 4)])
+        _run_case(fpv, oracle, fr, 320, 200, 4, False, fr[0])
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v

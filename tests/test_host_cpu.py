@@ -116,3 +116,33 @@ def test_unextract_matches_oracle(codec, oracle, synth):
     img = synth.noise_frames(1, 64, 48, seed=8)[0]
     for shift, be in ((0, False), (4, False), (4, True), (8, True)):
         assert np.array_equal(codec.unextract(img, 64, 48, shift, be), oracle.unextract(img, shift, be))
+
+
+def test_in_process_multi_device_round_robin(tmp_path, synth):
+    """Encoder shards batches over every visible device (batch b -> device b mod G).
+    The CPU shim can pose as several devices: the stream must not change."""
+    import subprocess
+    import sys
+    if not os.path.exists(SHIM):
+        pytest.skip("tests/shim not built")
+    code = r'''
+import sys, os, importlib, hashlib
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+from conftest import load_package
+load_package()
+synth = importlib.import_module("fpv_amd.synth"); codec = importlib.import_module("fpv_amd.codec").Codec(sys.argv[2])
+fr = synth.noise_frames(70, 64, 48, seed=9)
+print("SHA", hashlib.sha256(codec.encode_stream(fr, fr[0], 64, 48, threads=4).tobytes()).hexdigest())
+'''
+    script = tmp_path / "multi.py"
+    script.write_text(code)
+    root = os.path.dirname(HERE)
+    shas = []
+    for ndev, devs in ((1, None), (3, None), (4, "1,3")):
+        env = dict(os.environ, FPV_SHIM_DEVICES=str(ndev))
+        if devs:
+            env["FPV_DEVICES"] = devs
+        out = subprocess.run([sys.executable, str(script), root, SHIM], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout + out.stderr
+        shas.append([l for l in out.stdout.splitlines() if l.startswith("SHA")][0])
+    assert shas[0] == shas[1] == shas[2]

@@ -1260,6 +1260,14 @@ __global__ __launch_bounds__(64) void k_inverse(
 // chain redundantly on wave-uniform data; the other phases are data parallel.
 constexpr uint32_t kInvC = 256;
 
+// One-wave workgroups: LDS hand-offs between the phases only need this wave's
+// own LDS operations to have completed.  __syncthreads() would also drain the
+// vector-memory counter and so wait for the global prefetch issued just before.
+__device__ __forceinline__ void wave_lds_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
 __device__ __forceinline__ uint32_t inv_px(uint32_t n, uint32_t w, uint32_t d, uint32_t r) {
   const int t = (int)w + (int)d;
   const int lo = min((int)n, (int)w), hi = max((int)n, (int)w);
@@ -1312,12 +1320,30 @@ __global__ __launch_bounds__(64) void k_inverse_fast(
   uint32_t* xx = rr + kInvC;
   uint32_t w = 0;
 
+  // Global operands of a chunk (this lane's 4 pixels): fetched ONE CHUNK AHEAD, so
+  // that their latency hides behind the previous chunk's chain.
+  struct Fetch { uint32_t r4, l4, dh4, dl4; };
+  auto fetch = [&](uint32_t c0) {
+    Fetch f = {0, 0, 0, 0};
+    const uint32_t i = c0 + lane * 4;
+    if (i < npix) {
+      f.r4 = *reinterpret_cast<const uint32_t*>(hp + i);
+      if (!no_low) f.l4 = *reinterpret_cast<const uint32_t*>(lp + i);
+      if (use_delta) {
+        f.dh4 = *reinterpret_cast<const uint32_t*>(dhigh + i);
+        f.dl4 = *reinterpret_cast<const uint32_t*>(dlow + i);
+      }
+    }
+    return f;
+  };
+  Fetch cur = fetch(0);
+
   for (uint32_t c0 = 0; c0 < npix; c0 += kInvC) {
     const uint32_t cn = min(kInvC, npix - c0);
     const uint32_t j = lane * 4, i = c0 + j;
     // prep (all lanes, 4 pixels each)
     if (j < cn) {
-      const uint32_t r4 = *reinterpret_cast<const uint32_t*>(hp + i);
+      const uint32_t r4 = cur.r4;
       *reinterpret_cast<uint4*>(rr + j) =
           make_uint4((r4 << 8) & 0xff00u, r4 & 0xff00u, (r4 >> 8) & 0xff00u, (r4 >> 16) & 0xff00u);
       if (i >= xs + 4) {  // earlier groups go through the head path below
@@ -1327,7 +1353,8 @@ __global__ __launch_bounds__(64) void k_inverse_fast(
         *reinterpret_cast<uint4*>(dd + j) = make_uint4(n4.x - nw0, n4.y - n4.x, n4.z - n4.y, n4.w - n4.z);
       }
     }
-    __syncthreads();
+    const Fetch next = fetch(c0 + kInvC);  // in flight while the chain below runs
+    wave_lds_sync();
     // chain (wave-uniform)
     uint32_t jj = 0;
     for (; jj < cn && c0 + jj < xs + 4; jj += 4) {  // head: literals (cc:327) and the first group
@@ -1345,18 +1372,37 @@ __global__ __launch_bounds__(64) void k_inverse_fast(
       }
     }
     if (jj == 0 && cn == kInvC) {  // the common case: a whole chunk, fully unrolled
+      // 16 pixels per block; the operands of block q+1 are read from LDS before
+      // block q's chain runs (two static register sets), so no LDS latency is
+      // exposed between blocks.
+      uint4 n4[2][4], d4[2][4], r4[2][4];
 #pragma unroll
-      for (int q = 0; q < (int)kInvC; q += 4) {
-        const uint4 n4 = *reinterpret_cast<const uint4*>(nn + q);
-        const uint4 d4 = *reinterpret_cast<const uint4*>(dd + q);
-        const uint4 r4 = *reinterpret_cast<const uint4*>(rr + q);
-        uint4 x4;
-        x4.x = inv_px(n4.x, w, d4.x, r4.x);
-        x4.y = inv_px(n4.y, x4.x, d4.y, r4.y);
-        x4.z = inv_px(n4.z, x4.y, d4.z, r4.z);
-        x4.w = inv_px(n4.w, x4.z, d4.w, r4.w);
-        w = x4.w;
-        *reinterpret_cast<uint4*>(xx + q) = x4;
+      for (int k = 0; k < 4; k++) {
+        n4[0][k] = *reinterpret_cast<const uint4*>(nn + 4 * k);
+        d4[0][k] = *reinterpret_cast<const uint4*>(dd + 4 * k);
+        r4[0][k] = *reinterpret_cast<const uint4*>(rr + 4 * k);
+      }
+#pragma unroll
+      for (int q = 0; q < (int)kInvC / 16; q++) {
+        const int a = q & 1, b = a ^ 1;
+        if (q + 1 < (int)kInvC / 16) {
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            n4[b][k] = *reinterpret_cast<const uint4*>(nn + 16 * (q + 1) + 4 * k);
+            d4[b][k] = *reinterpret_cast<const uint4*>(dd + 16 * (q + 1) + 4 * k);
+            r4[b][k] = *reinterpret_cast<const uint4*>(rr + 16 * (q + 1) + 4 * k);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          uint4 x4;
+          x4.x = inv_px(n4[a][k].x, w, d4[a][k].x, r4[a][k].x);
+          x4.y = inv_px(n4[a][k].y, x4.x, d4[a][k].y, r4[a][k].y);
+          x4.z = inv_px(n4[a][k].z, x4.y, d4[a][k].z, r4[a][k].z);
+          x4.w = inv_px(n4[a][k].w, x4.z, d4[a][k].w, r4[a][k].w);
+          w = x4.w;
+          *reinterpret_cast<uint4*>(xx + 16 * q + 4 * k) = x4;
+        }
       }
     } else {
       for (; jj < cn; jj += 4) {
@@ -1372,23 +1418,24 @@ __global__ __launch_bounds__(64) void k_inverse_fast(
         *reinterpret_cast<uint4*>(xx + jj) = x4;
       }
     }
-    __syncthreads();
+    wave_lds_sync();
     // output (all lanes, 4 pixels each): ring update, delta^-1 + recombine (cc:335-344)
     if (j < cn) {
       const uint4 x4 = *reinterpret_cast<const uint4*>(xx + j);
       *reinterpret_cast<uint4*>(xr + (i & m)) = x4;
       uint32_t h4 = (x4.x >> 8) | (x4.y & 0xff00u) | ((x4.z & 0xff00u) << 8) | ((x4.w & 0xff00u) << 16);
-      uint32_t l4 = no_low ? 0u : *reinterpret_cast<const uint32_t*>(lp + i);
+      uint32_t l4 = cur.l4;
       if (use_delta) {
-        h4 = add4(h4, *reinterpret_cast<const uint32_t*>(dhigh + i));
-        l4 = add4(l4, *reinterpret_cast<const uint32_t*>(dlow + i));
+        h4 = add4(h4, cur.dh4);
+        l4 = add4(l4, cur.dl4);
       }
       uint2 o;
       o.x = __builtin_amdgcn_perm(h4, l4, 0x05010400u);
       o.y = __builtin_amdgcn_perm(h4, l4, 0x07030602u);
       *reinterpret_cast<uint2*>(outp + i) = o;
     }
-    __syncthreads();
+    cur = next;
+    wave_lds_sync();
   }
 }
 

@@ -1372,6 +1372,7 @@ __global__ __launch_bounds__(64) void k_inverse_fast(
       }
     }
     if (jj == 0 && cn == kInvC) {  // the common case: a whole chunk, fully unrolled
+      {
       // 16 pixels per block; the operands of block q+1 are read from LDS before
       // block q's chain runs (two static register sets), so no LDS latency is
       // exposed between blocks.
@@ -1403,6 +1404,7 @@ __global__ __launch_bounds__(64) void k_inverse_fast(
           w = x4.w;
           *reinterpret_cast<uint4*>(xx + 16 * q + 4 * k) = x4;
         }
+      }
       }
     } else {
       for (; jj < cn; jj += 4) {

@@ -5,7 +5,7 @@ pkg=load_package(); synth=importlib.import_module('fpv_amd.synth')
 from oracle.oracle import Oracle
 orc=Oracle()
 XS,YS=1280,800
-for n in (1, 64, 1024):
+for n in (64, 1024, 4096):
     base=synth.plasma_frames(min(n,8),XS,YS,bits=12)
     pred=pkg.Predictor(XS,YS,4,False,max_batch=n); pred.set_delta_raw(base[0])
     d=torch.from_numpy(base.reshape(base.shape[0],-1).view(np.int16)).cuda()

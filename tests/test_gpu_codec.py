@@ -58,3 +58,20 @@ def test_callback_order_and_payloads(codec, synth):
     assert mq >= 7
     ids = [g[0] for g in got]
     assert ids == [1000000] + list(range(1, 41)) + [2000000]
+
+
+@pytest.mark.parametrize("xs,ys", [(30, 22), (5, 3), (1, 7), (257, 9), (1284, 6)])
+def test_decoders_accept_odd_sizes(codec, oracle, xs, ys):
+    """Files written by the CPU reference may have any size (only ENCODING needs
+    multiples of 4): the byte-granular inverse kernel decodes them."""
+    rng = np.random.default_rng(xs * 1000 + ys)
+    fr = (np.cumsum(rng.integers(0, 40, (4, ys, xs)), axis=2) * 37 + rng.integers(0, 300, (4, ys, xs))).astype(np.uint16)
+    stream = oracle.encode_stream(fr, fr[0], xs, ys, 0, False)
+    want = oracle.decode_stream(stream)
+    assert np.array_equal(want, fr)
+    assert np.array_equal(codec.decode_stream(stream), want)
+    assert np.array_equal(codec.decode_stream(stream, batched=True, threads=2), want)
+    assert np.array_equal(codec.stream_decode(stream, xs, ys, 4, block=50), want)
+    if xs >= 4 and ys >= 4:
+        _, pv = codec.decode_stream(stream, with_previews=True)
+        assert pv.shape == (4, ys // 4, xs // 4)

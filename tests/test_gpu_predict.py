@@ -107,3 +107,36 @@ def test_alternate_kernel_paths(fpv, synth, oracle, env):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+def test_randomised_geometries_and_contents(fpv, oracle):
+    """Seeded sweep: random multiple-of-4 geometries, shifts, endianness and
+    content classes (noise, smooth, constant, near-constant, zero low plane,
+    8-bit data) -- flags of every kind must come out identical to the oracle."""
+    rng = np.random.default_rng(20240901)
+    seen = set()
+    for trial in range(24):
+        xs = int(rng.integers(1, 90)) * 4
+        ys = int(rng.integers(1, 40)) * 4
+        be = bool(rng.integers(0, 2))
+        shift = int(rng.choice([0, 0, 4, 8, 2, 6]))
+        n = 5
+        base = rng.integers(0, 65536, (n, ys, xs)).astype(np.uint16)
+        kind = trial % 6
+        if kind == 1:   # smooth ramps + little noise
+            yy, xx = np.mgrid[0:ys, 0:xs]
+            base = ((yy * 37 + xx * 53)[None] + rng.integers(0, 64, (n, ys, xs)) + 4000 * np.arange(n)[:, None, None]).astype(np.uint16)
+        elif kind == 2:  # constant frames, one with a single different pixel
+            base[:] = 0x2345
+            base[2, ys // 2, xs // 2] = 0x9abc
+            base[3, 0, 0] = 0x1111
+        elif kind == 3:  # zero low bytes
+            base &= 0xFF00
+        elif kind == 4:  # 8-bit data
+            base >>= 8
+        elif kind == 5:  # frame equals the delta frame
+            base[1:] = base[0]
+            base[3] = base[0] + 1
+        fl = _run_case(fpv, oracle, base, xs, ys, shift, be, base[0])
+        seen |= set(int(f) for f in fl)
+    assert {0, 1, 3, 4}.issubset(seen) or len(seen) >= 4, seen

@@ -103,8 +103,26 @@ tests/shim/libfpv_amd_cpushim.so: tests/shim/fpvhip_oracle_shim.o tests/shim/fpv
 	$(CXX) $(CXXFLAGS) -shared -Wl,-Bsymbolic $(HOST_SRC) tests/shim/fpvhip_oracle_shim.o tests/shim/fpv_oracle.o \
 	    $(BROTLI) -o $@
 
+# AddressSanitizer + UBSan build of the host codec over the CPU shim (sanitizers
+# are CPU-only on this pool): tools/asan_host_tests.sh runs the host tests on it.
+asan: build/asan/libfpv_amd_cpushim.so
+build/asan/libfpv_amd_cpushim.so: tests/shim/fpvhip_oracle_shim.c oracle/fpv_oracle.c $(HOST_SRC) $(HOST_HDR)
+	@mkdir -p build/asan
+	gcc -std=c99 -O1 -g -fPIC -fsanitize=address,undefined -fno-omit-frame-pointer -Iinclude -Ioracle -I$(BROTLI_I) -c tests/shim/fpvhip_oracle_shim.c -o build/asan/shim.o
+	gcc -std=c99 -O1 -g -fPIC -fsanitize=address,undefined -fno-omit-frame-pointer -Ioracle -I$(BROTLI_I) -c oracle/fpv_oracle.c -o build/asan/oracle.o
+	$(CXX) $(CXXFLAGS) -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -shared -Wl,-Bsymbolic $(HOST_SRC) build/asan/shim.o build/asan/oracle.o $(BROTLI) -o $@
+
+# ThreadSanitizer run of the threaded host paths (native driver; CPU only).
+tsan: build/tsan/driver
+	TSAN_OPTIONS=halt_on_error=1 build/tsan/driver
+build/tsan/driver: tests/shim/tsan_driver.cc tests/shim/fpvhip_oracle_shim.c oracle/fpv_oracle.c $(HOST_SRC) $(HOST_HDR)
+	@mkdir -p build/tsan
+	gcc -std=c99 -O1 -g -fsanitize=thread -Iinclude -Ioracle -I$(BROTLI_I) -c tests/shim/fpvhip_oracle_shim.c -o build/tsan/shim.o
+	gcc -std=c99 -O1 -g -fsanitize=thread -Ioracle -I$(BROTLI_I) -c oracle/fpv_oracle.c -o build/tsan/oracle.o
+	$(CXX) $(CXXFLAGS) -O1 -g -fsanitize=thread tests/shim/tsan_driver.cc $(HOST_SRC) build/tsan/shim.o build/tsan/oracle.o $(BROTLI) -o $@
+
 clean:
 	rm -rf $(LIBDIR) build tests/shim/*.so tests/shim/*.o
 	$(MAKE) -C oracle clean
 
-.PHONY: all product tools oracle shim refcli refcb clean
+.PHONY: all product tools oracle shim refcli refcb asan tsan clean

@@ -328,7 +328,9 @@ struct Encoder::Impl {
     for (;;) {
       if (gpu_q.empty()) {
         if (stop) return;
-        cv_dispatch.wait_for(l, std::chrono::milliseconds(2));
+        // system_clock -> pthread_cond_timedwait, which ThreadSanitizer understands
+        // (clockwait is not intercepted by this toolchain); only a flush timer.
+        cv_dispatch.wait_until(l, std::chrono::system_clock::now() + std::chrono::milliseconds(2));
         if (gpu_q.empty() && cur && cur->n > 0 &&
             std::chrono::steady_clock::now() - cur_touched > std::chrono::milliseconds(2)) {
           Batch* b = cur;

@@ -24,8 +24,6 @@ struct Geom {
   uint32_t lds_h_bytes;         // bytes of the high line buffer (16-aligned)
   uint32_t lds_hist_off;        // byte offset of the 3 LDS histograms
   uint32_t lds_bytes;           // total dynamic LDS of the forward kernel
-  uint32_t group;               // frames per workgroup of the fused kernel
-  uint32_t stream;              // use the barrier-free streaming kernel
   uint32_t strip_rows, strips;  // streaming kernel: rows per wave strip, strips per frame
   uint32_t ring_fwd, ring_base; // streaming kernel: LDS ring size (pow2), offset of strip pixel 0
   uint32_t nacc;                // streaming kernel: preview accumulator rows
@@ -36,7 +34,6 @@ struct Geom {
   uint32_t ring;                // inverse kernel: LDS ring size (power of two)
   uint32_t inv_ring;            // fast inverse kernel: ring size in pixels (power of two)
   int32_t shift, swap;          // Frame ctor arguments (swap = big_endian on LE host)
-  int32_t xcd_map;              // forward kernel: XCD-partitioned tile ranges (speed only)
   int32_t fwd_ok;               // forward kernels usable (dims multiples of 4, LDS fits)
 };
 

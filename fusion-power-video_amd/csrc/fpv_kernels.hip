@@ -162,9 +162,9 @@ __global__ __launch_bounds__(kThreads) void k_split_decoded(
 // frame before it transforms it.  A second read of every frame would cost a
 // third of the HBM traffic, so the forward path SPECULATES:
 //
-//   k_fused        one pass per frame: split, preview, delta and CG residuals
+//   k_stream       one pass per frame: split, preview, delta and CG residuals
 //                  under the speculated flags, AND the exact histograms of the
-//                  heuristics for that speculation, written as per-tile partials
+//                  heuristics for that speculation, written as per-strip partials
 //   k_decide_spec  reduces the partials, evaluates EstimateEntropy, compares
 //                  the true decision with the speculation; mis-speculated
 //                  frames go to list A (delta decision wrong: histograms of the
@@ -361,117 +361,6 @@ __device__ __forceinline__ void tile_or_low(const TileLds& L, uint32_t or_low) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) or_low |= __shfl_xor(or_low, off, 64);
   if ((threadIdx.x & 63) == 0 && or_low) atomicOr(L.s_or, or_low);
-}
-
-// Fused speculative pass.  Workgroup = one tile position x a group of
-// consecutive frames.  The pixel loads of frame f+1 are issued as soon as the
-// registers of frame f are consumed (end of phase A), so HBM reads stay in
-// flight across the LDS phase, the barriers and the stores of frame f.  With
-// CACHE the tile's delta bytes also stay in registers for the whole group
-// (they are the same for every frame).
-template <bool SWAP, bool CACHE>
-__global__ __launch_bounds__(kThreads, 4) void k_fused(
-    const uint16_t* __restrict__ frames, const uint8_t* __restrict__ dhigh,
-    const uint8_t* __restrict__ dlow, const uint8_t* __restrict__ spec_ptr,
-    uint8_t* __restrict__ high, uint8_t* __restrict__ low, uint8_t* __restrict__ pv_raw,
-    uint32_t* __restrict__ anylow, uint16_t* __restrict__ partials, Geom g,
-    uint32_t nframes, uint32_t group) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const TileLds L = tile_lds(smem, g);
-  const uint32_t tid = threadIdx.x;
-  uint32_t tile = blockIdx.x, fg = blockIdx.y;
-  if (g.xcd_map) {
-    const uint32_t b = blockIdx.x, x = b & 7u, j = b >> 3, k = g.tiles >> 3;
-    fg = j / k;
-    tile = x * k + (j - fg * k);
-  }
-  const TileCtx t = tile_ctx(g, tile);
-  const bool with_delta = dhigh != nullptr;
-  const uint32_t spec = *spec_ptr & (with_delta ? 3u : 2u);
-  const bool use_delta = spec & 1, use_cg = spec & 2;
-  const uint4 zero = make_uint4(0, 0, 0, 0);
-
-  uint4 dhc[CACHE ? kMaxIter : 1], dlc[CACHE ? kMaxIter : 1];
-  if (CACHE && use_delta) {
-#pragma unroll
-    for (int it = 0; it < kMaxIter; it++) {
-      const uint32_t seg = tid + it * kThreads;
-      if (seg < t.nseg) {
-        dhc[it] = *reinterpret_cast<const uint4*>(dhigh + t.s + (seg << 4));
-        if (g.shift != 8) dlc[it] = *reinterpret_cast<const uint4*>(dlow + t.s + (seg << 4));
-      }
-    }
-  }
-
-  const uint32_t f0 = fg * group, f1 = min(nframes, f0 + group);
-  uint4 pa[kMaxIter], pb[kMaxIter];  // the frame's pixels of this thread, 16 per pass
-#pragma unroll
-  for (int it = 0; it < kMaxIter; it++) {
-    const uint32_t seg = tid + it * kThreads;
-    if (seg < t.nseg) {
-      const uint16_t* src = frames + (size_t)f0 * g.npix + t.s + (seg << 4);
-      pa[it] = *reinterpret_cast<const uint4*>(src);
-      pb[it] = *reinterpret_cast<const uint4*>(src + 8);
-    }
-  }
-
-  for (uint32_t frame = f0; frame < f1; frame++) {
-    const size_t fbase = (size_t)frame * g.npix;
-    const uint16_t* img = frames + fbase;
-    for (int b = tid; b < kHistFused * 256; b += kThreads) L.hist[b] = 0;
-    if (tid == 0) *L.s_or = 0;
-    if (t.s > 0) load_halo<SWAP>(g, t, L, img, dhigh, use_delta);
-    __syncthreads();
-
-    uint32_t or_low = 0;
-#pragma unroll
-    for (int it = 0; it < kMaxIter; it++) {
-      const uint32_t seg = tid + it * kThreads;
-      if (seg < t.nseg) {
-        const uint32_t o = seg << 4;
-        uint4 dh = zero, dl = zero;
-        if (CACHE) {
-          dh = dhc[it];
-          dl = dlc[it];
-        } else if (use_delta) {
-          dh = *reinterpret_cast<const uint4*>(dhigh + t.s + o);
-          if (g.shift != 8) dl = *reinterpret_cast<const uint4*>(dlow + t.s + o);
-        }
-        seg_phase_a<SWAP, true>(g, t, L, o, pa[it], pb[it], dh, dl, use_delta, use_cg,
-                                high + fbase, low + fbase, &or_low);
-      }
-    }
-    if (frame + 1 < f1) {  // prefetch the next frame of the group
-#pragma unroll
-      for (int it = 0; it < kMaxIter; it++) {
-        const uint32_t seg = tid + it * kThreads;
-        if (seg < t.nseg) {
-          const uint16_t* src = img + g.npix + t.s + (seg << 4);
-          pa[it] = *reinterpret_cast<const uint4*>(src);
-          pb[it] = *reinterpret_cast<const uint4*>(src + 8);
-        }
-      }
-    }
-    tile_or_low(L, or_low);
-    __syncthreads();
-
-#pragma unroll
-    for (int it = 0; it < kMaxIter; it++) {
-      const uint32_t seg = tid + it * kThreads;
-      if (seg < t.nseg) seg_phase_b<true>(g, t, L, seg << 4, use_cg, high + fbase);
-    }
-    tile_preview(g, t, L, pv_raw + (size_t)frame * g.npv);
-    if (tid == 0 && *L.s_or) atomicOr(&anylow[frame], *L.s_or);
-    __syncthreads();
-
-    // partial histograms of this tile: plain 16-bit stores, no atomics
-    uint16_t* ph = partials + ((size_t)frame * g.tiles + tile) * (kHistFused * 256);
-    for (int b = tid; b < kHistFused * 256 / 2; b += kThreads) {
-      const uint2 v = *reinterpret_cast<const uint2*>(L.hist + 2 * b);
-      *reinterpret_cast<uint32_t*>(ph + 2 * b) = (v.x & 0xffffu) | (v.y << 16);
-    }
-    __syncthreads();  // LDS is reused by the next frame
-  }
 }
 
 // ---------------------------------------------------------------------------
@@ -914,7 +803,7 @@ __global__ __launch_bounds__(kThreads) void k_decide_spec(
     uint32_t* __restrict__ list_a, uint32_t* __restrict__ list_b, Geom g, int with_delta) {
   __shared__ uint32_t scratch[4];
   const uint32_t frame = blockIdx.x, tid = threadIdx.x;
-  const uint32_t nparts = g.stream ? g.strips : g.tiles;
+  const uint32_t nparts = g.strips;
   const uint16_t* ph = partials + (size_t)frame * nparts * (kHistFused * 256);
   uint32_t v[kHistFused] = {0, 0, 0};
 #pragma unroll 8
@@ -1510,16 +1399,11 @@ bool make_geom(uint32_t xs, uint32_t ys, int shift, int big_endian, Geom* g,
     g->ring_fwd = rf;
     g->nacc = (kStep + 4 * xs - 1) / (4 * xs) + 1;
     g->wave_lds = round_up(rf + g->nacc * g->pw * 4 + kHistFused * 128 * 4, 16);
-    g->stream = g->wave_lds <= 64 * 1024;
-    if (const char* e = getenv("FPV_STREAM")) g->stream = g->stream && atoi(e);
+    if (g->wave_lds > 64 * 1024) { *why = kWide; return false; }
     uint32_t wpc = (160 * 1024 - 1024) / g->wave_lds;
     g->stream_waves_per_cu = std::max(1u, std::min(12u, wpc));  // measured: 8-12 beat 16 (memory-system contention)
     if (const char* e = getenv("FPV_WAVES_PER_CU")) g->stream_waves_per_cu = std::max(1, atoi(e));
   }
-  g->xcd_map = 0;
-  if (const char* e = getenv("FPV_XCD_MAP")) g->xcd_map = atoi(e) && (g->tiles % 8 == 0);
-  g->group = 8;
-  if (const char* e = getenv("FPV_GROUP")) g->group = (uint32_t)std::max(1, atoi(e));
   g->nd = (g->npix + 14) / 15;
   g->ncg = g->npix > xs + 1 ? (g->npix - xs - 1 + 30) / 31 : 0;
   uint32_t samples = g->nd + g->ncg;
@@ -1560,7 +1444,7 @@ size_t fwd_workspace_bytes(const Geom& g, uint32_t max_frames) {
   b += round_up(max_frames, 256);                                // decision
   b += 2 * (size_t)round_up(max_frames * 4, 256);                // list A, list B
   b += round_up((size_t)max_frames * g.npv, 256);                // pv_raw
-  b += (size_t)max_frames * std::max(g.tiles, g.strips) * kHistFused * 256 * 2;  // partial histograms (u16)
+  b += (size_t)max_frames * g.strips * kHistFused * 256 * 2;  // partial histograms (u16)
   return b + 256 /* spec */ + 256;
 }
 
@@ -1583,7 +1467,7 @@ void carve_fwd_workspace(const Geom& g, uint32_t max_frames, void* base,
   ws->pv_raw = p;
   p += round_up((size_t)max_frames * g.npv, 256);
   ws->partials = reinterpret_cast<uint16_t*>(p);
-  p += (size_t)max_frames * std::max(g.tiles, g.strips) * kHistFused * 256 * 2;
+  p += (size_t)max_frames * g.strips * kHistFused * 256 * 2;
   ws->spec = p;
 }
 
@@ -1641,7 +1525,7 @@ static hipError_t predict_impl(const Geom& g, const uint16_t* d_frames,
       hipSuccess)
     return e;
   if (ev) hipEventRecord(ev[0], s);
-  if (g.stream) {
+  {
     static int ncu = 0;
     if (!ncu) {
       int dev = 0;
@@ -1676,18 +1560,6 @@ static hipError_t predict_impl(const Geom& g, const uint16_t* d_frames,
       else { FPV_LAUNCH_STREAM(false, false, false); if (with_delta) FPV_LAUNCH_STREAM(false, true, false); }
     }
 #undef FPV_LAUNCH_STREAM
-  } else {
-    const uint32_t groups = (nframes + g.group - 1) / g.group;
-    static const int cache = getenv("FPV_CACHE_DELTA") ? atoi(getenv("FPV_CACHE_DELTA")) : 0;
-    const dim3 grid = g.xcd_map ? dim3(g.tiles * groups) : dim3(g.tiles, groups);
-    if (cache)
-      k_fused<SWAP, true><<<grid, kThreads, g.lds_bytes, s>>>(
-          d_frames, d_dhigh, d_dlow, ws.spec, d_high, d_low, ws.pv_raw, ws.anylow, ws.partials, g,
-          nframes, g.group);
-    else
-      k_fused<SWAP, false><<<grid, kThreads, g.lds_bytes, s>>>(
-          d_frames, d_dhigh, d_dlow, ws.spec, d_high, d_low, ws.pv_raw, ws.anylow, ws.partials, g,
-          nframes, g.group);
   }
   if (ev) hipEventRecord(ev[1], s);
   k_decide_spec<<<nframes, kThreads, 0, s>>>(ws.partials, ws.spec, ws.decision, ws.counters,
@@ -1732,11 +1604,7 @@ hipError_t launch_predict(const Geom& g, const uint16_t* d_frames,
 #undef FPV_SF
     for (const void* f : sf)
       hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    const void* fns[6] = {reinterpret_cast<const void*>(&k_fused<true, true>),
-                          reinterpret_cast<const void*>(&k_fused<false, true>),
-                          reinterpret_cast<const void*>(&k_fused<true, false>),
-                          reinterpret_cast<const void*>(&k_fused<false, false>),
-                          reinterpret_cast<const void*>(&k_apply_list<true>),
+    const void* fns[2] = {reinterpret_cast<const void*>(&k_apply_list<true>),
                           reinterpret_cast<const void*>(&k_apply_list<false>)};
     for (const void* f : fns)
       hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);

@@ -1,0 +1,50 @@
+// TEST INFRASTRUCTURE ONLY: drives the host codec's threaded paths (encoder
+// batch pipeline, batched random-access decode) over the CPU shim so that the
+// whole thing can run under ThreadSanitizer (`make tsan`).
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "fusion_power_video.h"
+
+static void Append(const uint8_t* d, size_t n, void* p) {
+  std::vector<uint8_t>* v = static_cast<std::vector<uint8_t>*>(p);
+  v->insert(v->end(), d, d + n);
+}
+
+int main() {
+  const size_t xs = 64, ys = 48, n = 300;
+  std::vector<uint16_t> fr(n * xs * ys);
+  uint32_t s = 12345;
+  for (auto& v : fr) { s = s * 1664525u + 1013904223u; v = (s >> 16) & 0xfff; }
+  for (int threads : {0, 1, 3, 8}) {
+    std::vector<uint8_t> out;
+    {
+      fpvc::Encoder enc(threads, 4, false);
+      enc.Init(fr.data(), xs, ys, Append, &out);
+      for (size_t i = 0; i < n; i++) enc.CompressFrame(&fr[i * xs * ys], Append, &out);
+      enc.Finish(Append, &out);
+    }
+    fpvc::RandomAccessDecoder dec;
+    if (!dec.Init(out.data(), out.size()) || dec.numframes() != n) return 1;
+    std::vector<size_t> idx(n);
+    for (size_t i = 0; i < n; i++) idx[i] = n - 1 - i;
+    std::vector<uint16_t> back(n * xs * ys);
+    std::vector<uint16_t*> outp(n);
+    for (size_t i = 0; i < n; i++) outp[i] = &back[i * xs * ys];
+    if (!dec.DecodeFrames(idx.data(), n, outp.data(), threads)) return 2;
+    for (size_t i = 0; i < n; i++)
+      for (size_t k = 0; k < xs * ys; k++)
+        if (back[i * xs * ys + k] != (uint16_t)(fr[(n - 1 - i) * xs * ys + k] << 4)) return 3;
+    size_t got = 0;
+    fpvc::StreamingDecoder sd;
+    for (size_t pos = 0; pos < out.size(); pos += 1000)
+      sd.Decode(out.data() + pos, out.size() - pos < 1000 ? out.size() - pos : 1000,
+                [](bool ok, uint16_t*, size_t, size_t, void* p) { if (ok) ++*static_cast<size_t*>(p); }, &got);
+    if (got != n) return 4;
+    printf("threads %d ok, %zu bytes\n", threads, out.size());
+  }
+  return 0;
+}

@@ -87,13 +87,12 @@ def test_partial_batches_reuse_workspace(fpv, synth, oracle):
     p.close()
 
 
-@pytest.mark.parametrize("env", [{"FPV_STREAM": "0"}, {"FPV_STREAM": "0", "FPV_CACHE_DELTA": "1", "FPV_XCD_MAP": "1"},
-                                 {"FPV_STRIP_ROWS": "4"}, {"FPV_STRIP_ROWS": "12", "FPV_WAVES_PER_CU": "2"},
+@pytest.mark.parametrize("env", [{"FPV_STRIP_ROWS": "4"}, {"FPV_STRIP_ROWS": "80", "FPV_STRIP_MAJOR": "0"}, {"FPV_STRIP_ROWS": "12", "FPV_WAVES_PER_CU": "2"},
                                  {"FPV_INVERSE_SLOW": "1"}])
 def test_alternate_kernel_paths(fpv, synth, oracle, env):
-    """The tile-based fused kernel (used for very wide frames), odd strip sizes
-    (partial last steps, non-FAST streaming variant) and the generic inverse
-    kernel must give the same bits as the default paths."""
+    """Odd strip sizes (partial last steps, non-FAST streaming variant), the
+    frame-major task order and the generic inverse kernel must give the same
+    bits as the default paths."""
     import os
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)

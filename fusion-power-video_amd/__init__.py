@@ -67,6 +67,8 @@ def _declare_hip(lib):
     lib.fpvhip_time_copy_device.argtypes = [vp, vp, c.c_size_t, vp, i32]
     lib.fpvhip_time_inverse_device.restype = c.c_double
     lib.fpvhip_time_inverse_device.argtypes = [vp, vp, vp, vp, u32, vp, vp, i32]
+    lib.fpvhip_inverse_pass_stats.restype = i32
+    lib.fpvhip_inverse_pass_stats.argtypes = [vp, c.POINTER(c.c_uint32), i32]
     for name in ("fpvhip_set_delta_raw", "fpvhip_set_delta_decoded", "fpvhip_predict_submit",
                  "fpvhip_predict_wait", "fpvhip_inverse_submit", "fpvhip_inverse_wait",
                  "fpvhip_predict_device", "fpvhip_inverse_device"):
@@ -211,6 +213,12 @@ class Predictor:
         if ms < 0:
             raise FpvError("time_predict: " + _err(self.ctx))
         return (ms, list(km)) if per_kernel else ms
+
+    def inverse_pass_stats(self, reset=True):
+        """(supersteps, passes) of the speculative inverse kernel since the last reset."""
+        out = (ctypes.c_uint32 * 2)()
+        self._check(self.lib.fpvhip_inverse_pass_stats(self.ctx, out, int(reset)), "inverse_pass_stats")
+        return int(out[0]), int(out[1])
 
     def time_inverse(self, high, low, flags, out, iters):
         ms = self.lib.fpvhip_time_inverse_device(

@@ -51,6 +51,7 @@ struct fpvhip_ctx {
   uint8_t* d_dhigh = nullptr;
   uint8_t* d_dlow = nullptr;
   uint16_t* d_dtmp = nullptr;  // upload buffer for set_delta_*
+  uint32_t* d_inv_diag = nullptr;  // speculative inverse: supersteps, passes (diagnostics)
   bool have_delta = false;
   // workspace of the device-resident entry points
   void* d_ws = nullptr;
@@ -172,6 +173,8 @@ static fpvhip_ctx* create_impl(int device, const Geom& g, uint32_t max_batch,
     HIPOK(c, hipMalloc(reinterpret_cast<void**>(&c->d_dhigh), g.npix));
     HIPOK(c, hipMalloc(reinterpret_cast<void**>(&c->d_dlow), g.npix));
     HIPOK(c, hipMalloc(reinterpret_cast<void**>(&c->d_dtmp), (size_t)g.npix * 2));
+    HIPOK(c, hipMalloc(reinterpret_cast<void**>(&c->d_inv_diag), 16));
+    HIPOK(c, hipMemset(c->d_inv_diag, 0, 16));
     if (g.fwd_ok) {
       HIPOK(c, hipMalloc(&c->d_ws, fpvhip::fwd_workspace_bytes(g, max_batch)));
       fpvhip::carve_fwd_workspace(g, max_batch, c->d_ws, &c->ws);
@@ -217,7 +220,7 @@ void fpvhip_destroy(fpvhip_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);
   for (auto& s : c->slots) free_slot(&s);
-  hipFree(c->d_dhigh); hipFree(c->d_dlow); hipFree(c->d_dtmp); hipFree(c->d_ws);
+  hipFree(c->d_dhigh); hipFree(c->d_dlow); hipFree(c->d_dtmp); hipFree(c->d_ws); hipFree(c->d_inv_diag);
   for (auto& e : c->ev) if (e) hipEventDestroy(e);
   delete c;
 }
@@ -382,7 +385,7 @@ static int inverse_submit_impl(fpvhip_ctx* c, uint32_t slot, uint32_t nframes,
   HIPOK(c, fpvhip::launch_inverse(c->g, s.d_high, s.d_low,
                                   c->have_delta ? c->d_dhigh : nullptr,
                                   c->have_delta ? c->d_dlow : nullptr, s.d_flags,
-                                  nframes, s.d_pix, s.stream));
+                                  nframes, s.d_pix, s.stream, c->d_inv_diag));
   if (to_planes) {  // (pixel >> 8, pixel & 0xff) back into the plane staging buffers
     HIPOK(c, fpvhip::launch_split_planes(s.d_pix, s.d_high, s.d_low, nframes * np, s.stream));
     HIPOK(c, hipMemcpyAsync(s.h_high, s.d_high, nframes * np, hipMemcpyDeviceToHost, s.stream));
@@ -435,7 +438,7 @@ int fpvhip_inverse_device(fpvhip_ctx* c, const void* d_high, const void* d_low,
                c->have_delta ? c->d_dhigh : nullptr,
                c->have_delta ? c->d_dlow : nullptr,
                static_cast<const uint8_t*>(d_flags), nframes,
-               static_cast<uint16_t*>(d_frames), static_cast<hipStream_t>(stream)));
+               static_cast<uint16_t*>(d_frames), static_cast<hipStream_t>(stream), c->d_inv_diag));
   return 0;
 }
 
@@ -495,6 +498,15 @@ int fpvhip_debug_counters(fpvhip_ctx* c, uint32_t* out, uint32_t n) {
   if (!c || !out || n > 64 || !c->g.fwd_ok) return fail(c, "bad arguments");
   HIPOK(c, hipDeviceSynchronize());
   HIPOK(c, hipMemcpy(out, c->ws.counters, n * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int fpvhip_inverse_pass_stats(fpvhip_ctx* c, uint32_t* out, int reset) {
+  if (!c || !out) return fail(c, "bad arguments");
+  HIPOK(c, hipSetDevice(c->device));
+  HIPOK(c, hipDeviceSynchronize());
+  HIPOK(c, hipMemcpy(out, c->d_inv_diag, 8, hipMemcpyDeviceToHost));
+  if (reset) HIPOK(c, hipMemset(c->d_inv_diag, 0, 16));
   return 0;
 }
 

@@ -33,6 +33,8 @@ struct Geom {
   uint32_t stat_blocks;         // workgroups per frame of the stats kernel
   uint32_t ring;                // inverse kernel: LDS ring size (power of two)
   uint32_t inv_ring;            // fast inverse kernel: ring size in pixels (power of two)
+  uint32_t spec_k4;             // speculative inverse kernel: dwords (4 pixels) per lane and superstep, 0 = unusable
+  uint32_t spec_ring;           // speculative inverse kernel: ring size in bytes (power of two)
   int32_t shift, swap;          // Frame ctor arguments (swap = big_endian on LE host)
   int32_t fwd_ok;               // forward kernels usable (dims multiples of 4, LDS fits)
 };
@@ -85,11 +87,14 @@ hipError_t launch_predict(const Geom& g, const uint16_t* d_frames,
                           uint8_t* d_high, uint8_t* d_low, uint8_t* d_preview,
                           uint8_t* d_flags, hipStream_t s, hipEvent_t* ev);
 
-// Inverse predictor.  d_dhigh/d_dlow: delta planes or null.
+// Inverse predictor.  d_dhigh/d_dlow: delta planes or null.  d_diag, when not
+// null, points to two dwords the speculative kernel adds its superstep and pass
+// counts to (diagnostics).
 hipError_t launch_inverse(const Geom& g, const uint8_t* d_high,
                           const uint8_t* d_low, const uint8_t* d_dhigh,
                           const uint8_t* d_dlow, const uint8_t* d_flags,
-                          uint32_t nframes, uint16_t* d_frames, hipStream_t s);
+                          uint32_t nframes, uint16_t* d_frames, hipStream_t s,
+                          uint32_t* d_diag = nullptr);
 
 }  // namespace fpvhip
 #endif  // FPV_KERNELS_H_

@@ -1148,6 +1148,7 @@ __global__ __launch_bounds__(64) void k_inverse(
 // per four pixels -- no address arithmetic, no branches.  All lanes run the
 // chain redundantly on wave-uniform data; the other phases are data parallel.
 constexpr uint32_t kInvC = 256;
+constexpr uint32_t kSpecMaxK4 = 6;  // speculative inverse: at most 24 pixels per lane and superstep
 
 // One-wave workgroups: LDS hand-offs between the phases only need this wave's
 // own LDS operations to have completed.  __syncthreads() would also drain the
@@ -1330,11 +1331,209 @@ __global__ __launch_bounds__(64) void k_inverse_fast(
   }
 }
 
+
+// Speculative segmented inverse (xs % 4 == 0, npix % 4 == 0, xs >= 256).
+//
+// The inverse clamped gradient x[i] = r[i] + CG(x[i-xs], x[i-1], x[i-xs-1]) is a
+// serial chain in i (cc:327-332), but ONLY through w = x[i-1]: for a run of up
+// to xs consecutive pixels every north / north-west value belongs to pixels in
+// front of the run and is already final.  So one "superstep" takes S = 64*K
+// consecutive pixels (S <= xs), gives each LANE a segment of K pixels with all
+// its operands in registers, and lets every lane run its segment from a GUESSED
+// incoming w (the pixel above its west neighbour).  The guess is then checked
+// against what the previous lane actually produced; lanes whose input was wrong
+// rerun their segment from the corrected value, until no lane is wrong.
+//
+// This is exact, not approximate: lane 0's input is the final value of the
+// previous superstep, and once lane j's input equals lane j-1's output for all
+// j, every segment is the true chain by induction.  After pass p lanes 0..p-1
+// are final, so at most 64 passes (= the serial chain) are ever needed; on real
+// frames the chain forgets its input within a few pixels whenever w falls into
+// the predictor's flat range [min(n,nw), max(n,nw)], so a wrong guess rarely
+// survives a whole segment and 2-4 passes of K steps replace 64*K serial steps.
+template <int K4>
+__global__ __launch_bounds__(64) void k_inverse_spec(
+    const uint8_t* __restrict__ high, const uint8_t* __restrict__ low,
+    const uint8_t* __restrict__ dhigh, const uint8_t* __restrict__ dlow,
+    const uint8_t* __restrict__ flags, uint16_t* __restrict__ frames, Geom g,
+    uint32_t* __restrict__ pass_count) {
+  constexpr int K = 4 * K4;
+  constexpr uint32_t S = 64u * K;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint8_t* ring = smem;  // reconstructed high bytes, flat index & m
+  const uint32_t frame = blockIdx.x, lane = threadIdx.x;
+  const size_t fbase = (size_t)frame * g.npix;
+  const uint8_t* hp = high + fbase;
+  const uint8_t* lp = low ? low + fbase : nullptr;
+  uint16_t* outp = frames + fbase;
+  const uint32_t f = flags[frame];
+  const bool use_delta = (f & 1) && dhigh, use_cg = f & 2, no_low = (f & 4) || !lp;
+  const uint32_t xs = g.xs, npix = g.npix, m = g.spec_ring - 1;
+
+  // delta^-1 + recombine (cc:335-344) of the 4 pixels at flat index i
+  auto emit4 = [&](uint32_t i, uint32_t h4, uint32_t l4, uint32_t dh4, uint32_t dl4) {
+    if (use_delta) {
+      h4 = add4(h4, dh4);
+      l4 = add4(l4, dl4);
+    }
+    uint2 o;
+    o.x = __builtin_amdgcn_perm(h4, l4, 0x05010400u);
+    o.y = __builtin_amdgcn_perm(h4, l4, 0x07030602u);
+    *reinterpret_cast<uint2*>(outp + i) = o;
+  };
+
+  if (!use_cg) {  // no chain at all
+    for (uint32_t o = lane * 16; o < npix; o += 1024) {
+      const uint32_t nq = min(4u, (npix - o) >> 2);
+      for (uint32_t q = 0; q < nq; q++) {
+        const uint32_t i = o + 4 * q;
+        emit4(i, *reinterpret_cast<const uint32_t*>(hp + i),
+              no_low ? 0u : *reinterpret_cast<const uint32_t*>(lp + i),
+              use_delta ? *reinterpret_cast<const uint32_t*>(dhigh + i) : 0u,
+              use_delta ? *reinterpret_cast<const uint32_t*>(dlow + i) : 0u);
+      }
+    }
+    return;
+  }
+
+  // Head: the first xs + 1 pixels are literals (cc:327 starts at xs + 1); pixels
+  // xs+1 .. xs+3 are walked serially so that the supersteps start 4-aligned.
+  const uint32_t head = min(xs + 4, npix);
+  for (uint32_t o = lane * 4; o < head; o += 256)
+    *reinterpret_cast<uint32_t*>(ring + (o & m)) = *reinterpret_cast<const uint32_t*>(hp + o);
+  wave_lds_sync();
+  {
+    int w = ring[xs & m];
+    for (uint32_t i = xs + 1; i < head; i++) {
+      const int x = (ring[i & m] + cg_pred(ring[(i - xs) & m], w, ring[(i - xs - 1) & m])) & 0xff;
+      ring[i & m] = (uint8_t)x;  // every lane writes the same value
+      w = x;
+    }
+  }
+  wave_lds_sync();
+  for (uint32_t o = lane * 4; o < head; o += 256)
+    emit4(o, *reinterpret_cast<const uint32_t*>(ring + (o & m)),
+          no_low ? 0u : *reinterpret_cast<const uint32_t*>(lp + o),
+          use_delta ? *reinterpret_cast<const uint32_t*>(dhigh + o) : 0u,
+          use_delta ? *reinterpret_cast<const uint32_t*>(dlow + o) : 0u);
+  uint32_t w_prev = (uint32_t)ring[(head - 1) & m] << 8;  // wave-uniform: final x[s-1] << 8
+
+  // residual dwords of this lane's segment, fetched one superstep ahead
+  uint32_t rq[K4];
+  auto fetch_r = [&](uint32_t s, uint32_t* q) {
+#pragma unroll
+    for (int t = 0; t < K4; t++) {
+      const uint32_t i = s + lane * K + 4 * t;
+      q[t] = i < npix ? *reinterpret_cast<const uint32_t*>(hp + i) : 0u;
+    }
+  };
+  fetch_r(head, rq);
+  uint32_t npass = 0;
+
+  for (uint32_t s = head; s < npix; s += S) {
+    const uint32_t start = s + lane * K;
+    const bool active = start < npix;
+    // operands of the output phase (coalesced, 4 pixels per lane and round): in
+    // flight while the chain passes run
+    uint32_t l4[K4], dh4[K4], dl4[K4];
+#pragma unroll
+    for (int t = 0; t < K4; t++) {
+      const uint32_t i = s + (t * 64 + lane) * 4;
+      const bool inb = i < npix;
+      l4[t] = (inb && !no_low) ? *reinterpret_cast<const uint32_t*>(lp + i) : 0u;
+      dh4[t] = (inb && use_delta) ? *reinterpret_cast<const uint32_t*>(dhigh + i) : 0u;
+      dl4[t] = (inb && use_delta) ? *reinterpret_cast<const uint32_t*>(dlow + i) : 0u;
+    }
+    // segment operands into registers, everything as v << 8
+    uint32_t N[K], D[K], R[K], X[K];
+    {
+      const uint32_t nb = start - xs - 4;  // dword holding the north-west of the first pixel
+      uint32_t prev = __builtin_amdgcn_perm(0, *reinterpret_cast<const uint32_t*>(ring + (nb & m)), 0x0c0c030cu);
+      X[0] = prev;  // the guess: x[start - 1 - xs] << 8
+#pragma unroll
+      for (int t = 0; t < K4; t++) {
+        const uint32_t v = *reinterpret_cast<const uint32_t*>(ring + ((nb + 4 + 4 * t) & m));
+        const uint32_t r = rq[t];
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+          const uint32_t sel = 0x0c0c000cu | ((uint32_t)b << 8);
+          const uint32_t n = __builtin_amdgcn_perm(0, v, sel);
+          N[4 * t + b] = n;
+          D[4 * t + b] = n - prev;
+          R[4 * t + b] = __builtin_amdgcn_perm(0, r, sel);
+          prev = n;
+        }
+      }
+    }
+    uint32_t rnext[K4];
+    fetch_r(s + S, rnext);
+
+    // pass 1: every lane from its guess (lane 0 from the known value)
+    uint32_t in = lane == 0 ? w_prev : X[0];
+    {
+      uint32_t w = in;
+#pragma unroll
+      for (int k = 0; k < K; k++) X[k] = w = inv_px(N[k], w, D[k], R[k]);
+    }
+    npass++;
+    for (;;) {
+      uint32_t pred = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)X[K - 1], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+      if (lane == 0) pred = w_prev;
+      const bool bad = active && pred != in;
+      if (!__builtin_amdgcn_ballot_w64(bad)) break;
+      npass++;
+      if (bad) {
+        in = pred;
+        uint32_t w = in;
+#pragma unroll
+        for (int k = 0; k < K; k++) X[k] = w = inv_px(N[k], w, D[k], R[k]);
+      }
+    }
+    w_prev = (uint32_t)__builtin_amdgcn_readlane((int)X[K - 1], 63);
+
+    // reconstructed bytes into the ring (north of the next row, source of the output phase)
+#pragma unroll
+    for (int t = 0; t < K4; t++) {
+      const uint32_t o = __builtin_amdgcn_perm(X[4 * t + 1], X[4 * t], 0x0c0c0501u) |
+                         __builtin_amdgcn_perm(X[4 * t + 3], X[4 * t + 2], 0x05010c0cu);
+      *reinterpret_cast<uint32_t*>(ring + ((start + 4 * t) & m)) = o;
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int t = 0; t < K4; t++) {
+      const uint32_t i = s + (t * 64 + lane) * 4;
+      if (i < npix) emit4(i, *reinterpret_cast<const uint32_t*>(ring + (i & m)), l4[t], dh4[t], dl4[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < K4; t++) rq[t] = rnext[t];
+    wave_lds_sync();
+  }
+  if (pass_count && lane == 0) {  // diagnostics: supersteps and passes (bench / tests)
+    atomicAdd(&pass_count[0], (npix - head + S - 1) / S);
+    atomicAdd(&pass_count[1], npass);
+  }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------- host side ---
 
 static uint32_t round_up(uint32_t v, uint32_t a) { return (v + a - 1) / a * a; }
+
+// Speculative inverse: the largest supported segment length K = 4 * k4 with a
+// superstep of 64 * K pixels that fits into one image row (its north pixels must
+// lie in front of it).
+static void spec_geom(Geom* g) {
+  g->spec_k4 = 0;
+  g->spec_ring = 0;
+  if ((g->xs & 3) || (g->npix & 3) || g->xs < 256) return;
+  uint32_t k4 = std::min(kSpecMaxK4, g->xs / 256);
+  if (const char* e = getenv("FPV_SPEC_K4")) k4 = std::max(1u, std::min(k4, (uint32_t)atoi(e)));
+  g->spec_k4 = k4;
+  uint32_t r = 1;
+  while (r < g->xs + 256 * k4 + 16) r <<= 1;
+  g->spec_ring = r;
+}
 
 bool make_geom(uint32_t xs, uint32_t ys, int shift, int big_endian, Geom* g,
                const char** why) {
@@ -1413,6 +1612,7 @@ bool make_geom(uint32_t xs, uint32_t ys, int shift, int big_endian, Geom* g,
   while (ring < xs + 1 + kInvChunk + 4) ring <<= 1;
   g->ring = ring;
   { uint32_t ir = 1; while (ir < xs + 8 + kInvC) ir <<= 1; g->inv_ring = ir; }
+  spec_geom(g);
   g->fwd_ok = 1;
   return true;
 }
@@ -1431,6 +1631,7 @@ bool make_geom_decoder(uint32_t xs, uint32_t ys, Geom* g, const char** why) {
   if (ring > 128 * 1024) { *why = kWide; return false; }
   g->ring = ring;
   { uint32_t ir = 1; while (ir < xs + 8 + kInvC) ir <<= 1; g->inv_ring = ir; }
+  spec_geom(g);
   g->fwd_ok = 0;
   return true;
 }
@@ -1620,7 +1821,8 @@ hipError_t launch_predict(const Geom& g, const uint16_t* d_frames,
 hipError_t launch_inverse(const Geom& g, const uint8_t* d_high,
                           const uint8_t* d_low, const uint8_t* d_dhigh,
                           const uint8_t* d_dlow, const uint8_t* d_flags,
-                          uint32_t nframes, uint16_t* d_frames, hipStream_t s) {
+                          uint32_t nframes, uint16_t* d_frames, hipStream_t s,
+                          uint32_t* d_diag) {
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inverse<true>),
@@ -1631,15 +1833,36 @@ hipError_t launch_inverse(const Geom& g, const uint8_t* d_high,
                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
     attr_set = true;
   }
-  if ((g.xs & 3) == 0 && (g.npix & 3) == 0 && g.xs >= kInvC && !getenv("FPV_INVERSE_SLOW"))
+  // FPV_INVERSE = spec (default) | fast | slow selects the kernel (tests, A/B timing)
+  static const int mode = [] {
+    if (getenv("FPV_INVERSE_SLOW")) return 2;
+    const char* e = getenv("FPV_INVERSE");
+    if (!e) return 0;
+    return e[0] == 'f' ? 1 : e[0] == 's' && e[1] == 'l' ? 2 : 0;
+  }();
+  const bool aligned = (g.xs & 3) == 0 && (g.npix & 3) == 0;
+  if (mode == 0 && g.spec_k4) {
+#define FPV_LAUNCH_SPEC(K4)                                                                  \
+  case K4:                                                                                   \
+    k_inverse_spec<K4><<<nframes, 64, g.spec_ring, s>>>(d_high, d_low, d_dhigh, d_dlow,      \
+                                                        d_flags, d_frames, g, d_diag);       \
+    break;
+    switch (g.spec_k4) {
+      FPV_LAUNCH_SPEC(1) FPV_LAUNCH_SPEC(2) FPV_LAUNCH_SPEC(3)
+      FPV_LAUNCH_SPEC(4) FPV_LAUNCH_SPEC(5) FPV_LAUNCH_SPEC(6)
+      default: return hipErrorInvalidValue;
+    }
+#undef FPV_LAUNCH_SPEC
+  } else if (mode != 2 && aligned && g.xs >= kInvC) {
     k_inverse_fast<<<nframes, 64, (g.inv_ring + 4 * kInvC) * 4, s>>>(d_high, d_low, d_dhigh, d_dlow,
                                                                      d_flags, d_frames, g);
-  else if ((g.xs & 3) == 0 && (g.npix & 3) == 0)
+  } else if (aligned) {
     k_inverse<true><<<nframes, 64, g.ring, s>>>(d_high, d_low, d_dhigh, d_dlow,
                                                 d_flags, d_frames, g);
-  else
+  } else {
     k_inverse<false><<<nframes, 64, g.ring, s>>>(d_high, d_low, d_dhigh, d_dlow,
                                                  d_flags, d_frames, g);
+  }
   return hipGetLastError();
 }
 

@@ -1,0 +1,122 @@
+"""GPU parity of the speculative segmented inverse kernel (k_inverse_spec, the
+replacement of DecompressImage's serial loop cc:326-333) against the oracle.
+
+The kernel guesses each segment's incoming pixel and reruns segments until every
+guess is verified, so the interesting inputs are the ones where guesses fail:
+random residuals with the CG flag forced on (worst case: up to 64 passes), odd
+superstep tails, every segment length, flags of every kind."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _inverse_case(fpv, oracle, high, low, flags, xs, ys, delta16=None):
+    import torch
+    n = high.shape[0]
+    p = fpv.Predictor(xs, ys, 0, False, max_batch=n)
+    if delta16 is not None:
+        p.set_delta_decoded(delta16)
+    th = torch.from_numpy(high.reshape(n, -1)).cuda()
+    tl = torch.from_numpy(low.reshape(n, -1)).cuda()
+    tf = torch.from_numpy(np.asarray(flags, dtype=np.uint8)).cuda()
+    p.inverse_pass_stats(reset=True)
+    rec = p.inverse(th, tl, tf)
+    torch.cuda.synchronize()
+    stats = p.inverse_pass_stats()
+    rec = rec.cpu().view(torch.int16).numpy().view(np.uint16)
+    for k in range(n):
+        exp = oracle.inverse(high[k].reshape(-1), None if flags[k] & 4 else low[k].reshape(-1),
+                             delta16, xs, ys, int(flags[k]))
+        assert np.array_equal(rec[k].reshape(-1), np.asarray(exp).reshape(-1)), f"frame {k} (flags {flags[k]}) differs"
+    p.close()
+    return stats
+
+
+@pytest.mark.parametrize("xs,ys", [(256, 8), (260, 12), (320, 200), (1280, 16), (1284, 8), (1920, 12), (4096, 4), (2560, 4)])
+def test_random_residuals_every_flag(fpv, oracle, xs, ys):
+    """Uniform random planes: guesses are almost never right, the pass loop runs
+    long; all eight flag values, with a delta frame."""
+    rng = np.random.default_rng(xs * 7 + ys)
+    n = 8
+    high = rng.integers(0, 256, (n, ys, xs), dtype=np.uint8)
+    low = rng.integers(0, 256, (n, ys, xs), dtype=np.uint8)
+    delta16 = rng.integers(0, 65536, ys * xs).astype(np.uint16)
+    flags = np.arange(n, dtype=np.uint8)
+    steps, passes = _inverse_case(fpv, oracle, high, low, flags, xs, ys, delta16)
+    if (ys * xs) % 4 == 0 and xs % 4 == 0:
+        assert steps > 0 and passes >= steps       # the speculative kernel ran (CG frames only)
+
+
+def test_structured_residuals(fpv, oracle):
+    """Residual planes with long runs of zeros (identity steps: a wrong guess is
+    never forgotten), steps, and saturating values."""
+    xs, ys = 1280, 24
+    rng = np.random.default_rng(5)
+    n = 6
+    high = np.zeros((n, ys, xs), dtype=np.uint8)
+    high[0] = 0                                   # all zero: x stays at the literal row
+    high[1, 0] = rng.integers(0, 256, xs)         # random first row, zero residuals below
+    high[2] = (rng.integers(0, 100, (ys, xs)) == 0) * rng.integers(1, 256, (ys, xs))   # sparse
+    high[3] = 255                                 # constant -1 steps: wraps mod 256
+    high[4] = rng.integers(0, 2, (ys, xs)) * 128  # 0 / 128
+    high[5, :, ::7] = 1
+    low = rng.integers(0, 256, (n, ys, xs), dtype=np.uint8)
+    _inverse_case(fpv, oracle, high, low, np.full(n, 2, np.uint8), xs, ys)
+
+
+@pytest.mark.parametrize("k4", [1, 2, 3, 4, 5, 6])
+def test_every_segment_length(fpv, synth, oracle, k4):
+    """FPV_SPEC_K4 forces the segment length (4*k4 pixels per lane); real
+    predictor output (plasma) plus noise, odd tail (npix - head not a multiple of
+    the superstep)."""
+    import torch
+    os.environ["FPV_SPEC_K4"] = str(k4)
+    try:
+        xs, ys = 1536, 20
+        fr = np.concatenate([synth.plasma_frames(3, xs, ys, bits=12, seed=9),
+                             synth.noise_frames(2, xs, ys, seed=4) >> 4])
+        n = fr.shape[0]
+        p = fpv.Predictor(xs, ys, 4, False, max_batch=n)
+        p.set_delta_raw(fr[0])
+        d = torch.from_numpy(fr.reshape(n, -1).view(np.int16)).cuda().view(torch.uint16)
+        high, low, pv, flags = p.predict(d)
+        flags = (flags | 2)                      # force the chain on every frame
+        dh, dl, _ = oracle.split(fr[0], 4, False)
+        delta16 = (dh.astype(np.uint16) << 8) | dl
+        p.set_delta_decoded(delta16)
+        rec = p.inverse(high, low, flags)
+        torch.cuda.synchronize()
+        rec = rec.cpu().view(torch.int16).numpy().view(np.uint16)
+        h, l, f = high.cpu().numpy(), low.cpu().numpy(), flags.cpu().numpy()
+        for k in range(n):
+            exp = oracle.inverse(h[k], None if f[k] & 4 else l[k], delta16, xs, ys, int(f[k]))
+            assert np.array_equal(rec[k].reshape(-1), np.asarray(exp).reshape(-1)), f"frame {k}"
+        p.close()
+    finally:
+        os.environ.pop("FPV_SPEC_K4", None)
+
+
+def test_pass_counts_separate_easy_from_hard(fpv, synth, oracle):
+    """Diagnostics: real predictor residuals need few passes per superstep, random
+    residuals many (but never more than 64)."""
+    import torch
+    xs, ys = 1280, 64
+    fr = synth.plasma_frames(4, xs, ys, bits=12, seed=3)
+    p = fpv.Predictor(xs, ys, 4, False, max_batch=4)
+    p.set_delta_raw(fr[0])
+    d = torch.from_numpy(fr.reshape(4, -1).view(np.int16)).cuda().view(torch.uint16)
+    high, low, pv, flags = p.predict(d)
+    dh, dl, _ = oracle.split(fr[0], 4, False)
+    p.set_delta_decoded((dh.astype(np.uint16) << 8) | dl)
+    p.inverse_pass_stats(reset=True)
+    p.inverse(high, low, flags)
+    steps, passes = p.inverse_pass_stats()
+    assert steps > 0 and passes / steps < 16, (steps, passes)
+    rnd = torch.randint(0, 256, high.shape, dtype=torch.uint8, device="cuda")
+    p.inverse(rnd, low, torch.full_like(flags, 2))
+    steps2, passes2 = p.inverse_pass_stats()
+    assert steps2 > 0 and passes / steps < passes2 / steps2 <= 64, (steps2, passes2)
+    p.close()

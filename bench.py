@@ -125,6 +125,30 @@ def main():
     achieved = n * ALG_BYTES_PER_FRAME / dom_s / 1e9
     flags = out[3].cpu().numpy()
 
+    # Decode direction on the same batch (secondary figure, not `value`): the inverse
+    # predictor (DecompressImage's pixel loops, cc:326-344) over the planes just made.
+    inv = None
+    if rank == 0:
+        # the decoded delta frame is the left-aligned delta image (cc:437-443 then cc:340-341)
+        pred.set_delta_decoded((base[0].astype(np.uint16) << SHIFT).astype(np.uint16))
+        rec = torch.empty((n, NPIX), dtype=torch.uint16, device=dev)
+        pred.inverse_pass_stats(reset=True)
+        pred.inverse(out[0], out[1], out[3], out=rec)
+        torch.cuda.synchronize()
+        st = pred.inverse_pass_stats()
+        exact = bool((rec.view(torch.int16) == (d_frames.view(torch.int16).view(n, NPIX) << SHIFT)).all())
+        it = max(args.steps // 2, 3)
+        inv_ms = pred.time_inverse(out[0], out[1], out[3], rec, it) / it
+        inv_bytes = n * 4 * NPIX                                  # B_dec = 4 * P
+        inv = {"kernel": "k_inverse_spec", "frames_per_s": round(n / inv_ms * 1e3, 1),
+               "ms_per_batch": round(inv_ms, 4), "bound": "hbm",
+               "achieved": round(inv_bytes / inv_ms / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+               "frac": round(inv_bytes / inv_ms / 1e6 / HBM_PEAK_GBPS, 4),
+               "algorithmic_bytes_per_launch": inv_bytes,
+               "passes_per_superstep": round(st[1] / max(st[0], 1), 3),
+               "roundtrip_bit_exact": exact}
+        del rec
+
     if rank == 0:
         fps = world * n * args.steps / elapsed
         res = {
@@ -145,6 +169,8 @@ def main():
                          "algorithmic_bytes_per_launch": n * ALG_BYTES_PER_FRAME,
                          "measured_copy_GBps": round(copy_gbps, 1)},
         }
+        if inv is not None:
+            res["inverse"] = inv
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):
             try:

@@ -19,12 +19,14 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 
 namespace fpvhip {
 
 namespace {
 
 constexpr int kThreads = 256;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------- helpers --
 
@@ -96,13 +98,25 @@ __device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t* scratch) {
   return scratch[0] + scratch[1] + scratch[2] + scratch[3];
 }
 
-// Streaming copy, 16 B per lane: the measured HBM ceiling the predictor kernels
-// are compared with (bench only).
-__global__ __launch_bounds__(kThreads) void k_copy(const uint4* __restrict__ src,
-                                                  uint4* __restrict__ dst, size_t n16) {
-  const size_t stride = (size_t)gridDim.x * kThreads;
-  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n16; i += stride)
-    dst[i] = src[i];
+// Streaming copy, 16 B per lane, non-temporal, one contiguous 256 KiB chunk per
+// workgroup and turn: the fastest of the copy shapes tried on MI355X
+// (tools/exp/bw2.hip: 5.3-5.5 TB/s read+write, grid-stride copies reach 4.3-5.0).
+// It is the measured HBM ceiling the predictor kernels are compared with (bench only).
+constexpr size_t kCopyChunk16 = (256u << 10) / 16;
+__global__ __launch_bounds__(kThreads) void k_copy(const u32x4* __restrict__ src,
+                                                  u32x4* __restrict__ dst, size_t n16) {
+  for (size_t c = blockIdx.x; c * kCopyChunk16 < n16; c += gridDim.x) {
+    const size_t b = c * kCopyChunk16, e = min(b + kCopyChunk16, n16);
+    size_t i = b + threadIdx.x;
+    for (; i + 3 * kThreads < e; i += 4 * kThreads) {
+      u32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) v[u] = __builtin_nontemporal_load(src + i + u * kThreads);
+#pragma unroll
+      for (int u = 0; u < 4; u++) __builtin_nontemporal_store(v[u], dst + i + u * kThreads);
+    }
+    for (; i < e; i += kThreads) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+  }
 }
 
 // ------------------------------------------------------------- raw split ---
@@ -390,7 +404,6 @@ constexpr uint32_t kStep = 1024;  // pixels per wave step
 #ifndef FPV_NT
 #define FPV_NT 1
 #endif
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint4 ld_stream(const void* p) {
 #if FPV_NT
   const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
@@ -1418,58 +1431,71 @@ __global__ __launch_bounds__(64) void k_inverse_spec(
           use_delta ? *reinterpret_cast<const uint32_t*>(dlow + o) : 0u);
   uint32_t w_prev = (uint32_t)ring[(head - 1) & m] << 8;  // wave-uniform: final x[s-1] << 8
 
+  // Every global access of the superstep loop is unconditional (clamped index,
+  // planes that do not exist replaced by a readable dummy and masked to zero), so
+  // that the loads stay in flight behind counted vmcnt waits instead of being
+  // drained at a branch.  Only the last, partial superstep predicates its stores.
+  const uint8_t* lsrc = no_low ? hp : lp;
+  const uint8_t* dhsrc = use_delta ? dhigh : hp;
+  const uint8_t* dlsrc = use_delta ? dlow : hp;
+  const uint32_t lmask = no_low ? 0u : ~0u, dmask = use_delta ? ~0u : 0u;
+  const uint32_t last4 = npix - 4;  // npix % 4 == 0 and npix >= head >= 4
+
   // residual dwords of this lane's segment, fetched one superstep ahead
   uint32_t rq[K4];
-  auto fetch_r = [&](uint32_t s, uint32_t* q) {
+  auto fetch_r = [&](uint32_t s0, uint32_t* q) {
 #pragma unroll
     for (int t = 0; t < K4; t++) {
-      const uint32_t i = s + lane * K + 4 * t;
-      q[t] = i < npix ? *reinterpret_cast<const uint32_t*>(hp + i) : 0u;
+      const uint32_t i = s0 + lane * K + 4 * t;
+      const uint32_t v = *reinterpret_cast<const uint32_t*>(hp + min(i, last4));
+      q[t] = i < npix ? v : 0u;
     }
   };
   fetch_r(head, rq);
   uint32_t npass = 0;
 
-  for (uint32_t s = head; s < npix; s += S) {
-    const uint32_t start = s + lane * K;
-    const bool active = start < npix;
+  auto superstep = [&](uint32_t s0, auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    const uint32_t start = s0 + lane * K;
+    const bool active = FULL || start < npix;
     // operands of the output phase (coalesced, 4 pixels per lane and round): in
     // flight while the chain passes run
     uint32_t l4[K4], dh4[K4], dl4[K4];
 #pragma unroll
     for (int t = 0; t < K4; t++) {
-      const uint32_t i = s + (t * 64 + lane) * 4;
-      const bool inb = i < npix;
-      l4[t] = (inb && !no_low) ? *reinterpret_cast<const uint32_t*>(lp + i) : 0u;
-      dh4[t] = (inb && use_delta) ? *reinterpret_cast<const uint32_t*>(dhigh + i) : 0u;
-      dl4[t] = (inb && use_delta) ? *reinterpret_cast<const uint32_t*>(dlow + i) : 0u;
+      const uint32_t i = s0 + (t * 64 + lane) * 4;
+      const uint32_t ic = FULL ? i : min(i, last4);
+      l4[t] = *reinterpret_cast<const uint32_t*>(lsrc + ic) & lmask;
+      dh4[t] = *reinterpret_cast<const uint32_t*>(dhsrc + ic) & dmask;
+      dl4[t] = *reinterpret_cast<const uint32_t*>(dlsrc + ic) & dmask;
     }
     // segment operands into registers, everything as v << 8
     uint32_t N[K], D[K], R[K], X[K];
+    uint32_t guess;
     {
       const uint32_t nb = start - xs - 4;  // dword holding the north-west of the first pixel
-      uint32_t prev = __builtin_amdgcn_perm(0, *reinterpret_cast<const uint32_t*>(ring + (nb & m)), 0x0c0c030cu);
-      X[0] = prev;  // the guess: x[start - 1 - xs] << 8
+      uint32_t nd[K4 + 1];
+#pragma unroll
+      for (int t = 0; t <= K4; t++) nd[t] = *reinterpret_cast<const uint32_t*>(ring + ((nb + 4 * t) & m));
+      uint32_t prev = __builtin_amdgcn_perm(0, nd[0], 0x0c0c030cu);
+      guess = prev;  // x[start - 1 - xs] << 8
 #pragma unroll
       for (int t = 0; t < K4; t++) {
-        const uint32_t v = *reinterpret_cast<const uint32_t*>(ring + ((nb + 4 + 4 * t) & m));
-        const uint32_t r = rq[t];
 #pragma unroll
         for (int b = 0; b < 4; b++) {
           const uint32_t sel = 0x0c0c000cu | ((uint32_t)b << 8);
-          const uint32_t n = __builtin_amdgcn_perm(0, v, sel);
+          const uint32_t n = __builtin_amdgcn_perm(0, nd[t + 1], sel);
           N[4 * t + b] = n;
           D[4 * t + b] = n - prev;
-          R[4 * t + b] = __builtin_amdgcn_perm(0, r, sel);
+          R[4 * t + b] = __builtin_amdgcn_perm(0, rq[t], sel);
           prev = n;
         }
       }
     }
-    uint32_t rnext[K4];
-    fetch_r(s + S, rnext);
+    fetch_r(s0 + S, rq);  // next superstep's residuals (rq was consumed above)
 
     // pass 1: every lane from its guess (lane 0 from the known value)
-    uint32_t in = lane == 0 ? w_prev : X[0];
+    uint32_t in = lane == 0 ? w_prev : guess;
     {
       uint32_t w = in;
 #pragma unroll
@@ -1499,15 +1525,25 @@ __global__ __launch_bounds__(64) void k_inverse_spec(
       *reinterpret_cast<uint32_t*>(ring + ((start + 4 * t) & m)) = o;
     }
     wave_lds_sync();
+    uint32_t h4[K4];
 #pragma unroll
-    for (int t = 0; t < K4; t++) {
-      const uint32_t i = s + (t * 64 + lane) * 4;
-      if (i < npix) emit4(i, *reinterpret_cast<const uint32_t*>(ring + (i & m)), l4[t], dh4[t], dl4[t]);
+    for (int t = 0; t < K4; t++)
+      h4[t] = *reinterpret_cast<const uint32_t*>(ring + ((s0 + (t * 64 + lane) * 4) & m));
+#pragma unroll
+    for (int t = 0; t < K4; t++) {  // delta^-1 + recombine (cc:335-344); absent planes are zeros
+      const uint32_t i = s0 + (t * 64 + lane) * 4;
+      const uint32_t hh = add4(h4[t], dh4[t]), ll = add4(l4[t], dl4[t]);
+      uint2 o;
+      o.x = __builtin_amdgcn_perm(hh, ll, 0x05010400u);
+      o.y = __builtin_amdgcn_perm(hh, ll, 0x07030602u);
+      if (FULL || i < npix) *reinterpret_cast<uint2*>(outp + i) = o;
     }
-#pragma unroll
-    for (int t = 0; t < K4; t++) rq[t] = rnext[t];
     wave_lds_sync();
-  }
+  };
+
+  uint32_t s = head;
+  for (; s + S <= npix; s += S) superstep(s, std::true_type());
+  if (s < npix) superstep(s, std::false_type());
   if (pass_count && lane == 0) {  // diagnostics: supersteps and passes (bench / tests)
     atomicAdd(&pass_count[0], (npix - head + S - 1) / S);
     atomicAdd(&pass_count[1], npass);
@@ -1571,18 +1607,20 @@ bool make_geom(uint32_t xs, uint32_t ys, int shift, int big_endian, Geom* g,
   g->lds_hist_off = round_up(g->lds_h_bytes + g->tile_px / 2, 16);
   g->lds_bytes = g->lds_hist_off + kHistFused * 256 * 4 + 16;
   if (g->lds_bytes > 160 * 1024 - 64) { *why = kWide; return false; }
-  // streaming kernel: strips of about 40K pixels (whole preview rows), one wave each
+  // streaming kernel: strips of about 100K pixels (whole preview rows), one wave each
   {
     // Prefer a strip height that divides ys and whose pixel count is a multiple
-    // of the 1024-pixel step (the FAST kernel needs both); about 40K pixels.
-    uint32_t srows = ((40960 + xs - 1) / xs + 3) & ~3u;
+    // of the 1024-pixel step (the FAST kernel needs both); about 100K pixels
+    // (measured on 1280x800: 80..160 rows beat 32: fewer halo rows and partials).
+    const double kTarget = 102400.0;
+    uint32_t srows = (((uint32_t)kTarget + xs - 1) / xs + 3) & ~3u;
     {
       uint32_t best = 0;
       double best_cost = 1e30;
       for (uint32_t r = 4; r <= ys; r += 4) {
         if (ys % r || ((uint64_t)r * xs) % kStep) continue;
         const double px = (double)r * xs;
-        const double cost = px < 40960 ? 40960 / px : px / 40960;  // distance from the target
+        const double cost = px < kTarget ? kTarget / px : px / kTarget;  // distance from the target
         if (cost < best_cost) { best_cost = cost; best = r; }
       }
       if (best && best_cost < 4.0) srows = best;
@@ -1600,7 +1638,7 @@ bool make_geom(uint32_t xs, uint32_t ys, int shift, int big_endian, Geom* g,
     g->wave_lds = round_up(rf + g->nacc * g->pw * 4 + kHistFused * 128 * 4, 16);
     if (g->wave_lds > 64 * 1024) { *why = kWide; return false; }
     uint32_t wpc = (160 * 1024 - 1024) / g->wave_lds;
-    g->stream_waves_per_cu = std::max(1u, std::min(12u, wpc));  // measured: 8-12 beat 16 (memory-system contention)
+    g->stream_waves_per_cu = std::max(1u, std::min(8u, wpc));  // measured: 8 beats 12 beats 16 (memory-system contention)
     if (const char* e = getenv("FPV_WAVES_PER_CU")) g->stream_waves_per_cu = std::max(1, atoi(e));
   }
   g->nd = (g->npix + 14) / 15;
@@ -1677,8 +1715,8 @@ hipError_t init_fwd_workspace(const FwdWorkspace& ws, hipStream_t s) {
 }
 
 hipError_t launch_copy(const void* src, void* dst, size_t bytes, hipStream_t s) {
-  k_copy<<<256 * 8, kThreads, 0, s>>>(static_cast<const uint4*>(src), static_cast<uint4*>(dst),
-                                      bytes / 16);
+  k_copy<<<256 * 32, kThreads, 0, s>>>(static_cast<const u32x4*>(src), static_cast<u32x4*>(dst),
+                                       bytes / 16);
   return hipGetLastError();
 }
 

@@ -116,7 +116,9 @@ class Codec:
         out = np.zeros(max(nframes, 1) * xs * ys, np.uint16)
         got = self.lib.fpvc_stream_decode(data, data.size, block, out, nframes)
         if got < 0:
-            raise RuntimeError("stream_decode failed")
+            err = RuntimeError("stream_decode failed")
+            err.delivered = out[:(-got - 1) * xs * ys].reshape(-got - 1, ys, xs)  # frames in front of the failure
+            raise err
         return out[:got * xs * ys].reshape(got, ys, xs)
 
     def unextract(self, img, xs, ys, shift=0, big_endian=False):

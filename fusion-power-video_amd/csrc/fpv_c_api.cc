@@ -106,7 +106,7 @@ long fpvc_stream_decode(const uint8_t* data, size_t size, size_t block,
                  s->n++;
                },
                &st);
-    if (st.bad) return -1;
+    if (st.bad) return -1 - static_cast<long>(st.n);
   }
   return static_cast<long>(st.n);
 }

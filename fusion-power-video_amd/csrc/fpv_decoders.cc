@@ -174,22 +174,22 @@ bool InverseEngine::Decode(const uint8_t* in, size_t size, const uint16_t** fram
 }
 
 bool InverseEngine::DecodeBatch(const uint8_t* const* ins, const size_t* sizes, size_t n,
-                                uint16_t* const* outs, size_t threads) {
+                                const Sink& sink, size_t threads) {
   if (threads == 0) threads = 1;
   // Two slots alternate: while the GPU inverts batch g, the host threads
   // Brotli-decode batch g+1 into the other slot.
   struct Flight { int slot = -1; size_t first = 0, count = 0; };
   Flight prev;
   std::vector<uint8_t> flags(batch_);
+  std::vector<char> good(batch_);
   bool ok = true;
   auto finish = [&](Flight& f) {
     if (f.slot < 0) return;
     const uint16_t* px = nullptr;
     if (fpvhip_inverse_wait(ctx_, (uint32_t)f.slot, &px)) {
       ok = FPV_FAILURE(fpvhip_last_error(ctx_));
-    } else {
-      for (size_t i = 0; i < f.count; i++)
-        memcpy(outs[f.first + i], px + i * npix_, npix_ * 2);
+    } else if (ok) {
+      for (size_t i = 0; i < f.count; i++) sink(f.first + i, px + i * npix_);
     }
     Release(f.slot);
     f.slot = -1;
@@ -197,14 +197,19 @@ bool InverseEngine::DecodeBatch(const uint8_t* const* ins, const size_t* sizes, 
   for (size_t first = 0; first < n && ok; first += batch_) {
     const size_t count = std::min<size_t>(batch_, n - first);
     const int s = AcquireSlot();
+    // A slot's pinned memory is allocated on first touch, and calls on a context
+    // must not race: touch it here, before the worker threads use it.
+    if (!fpvhip_stage_plane(ctx_, (uint32_t)s, 0, 0)) {
+      Release(s);
+      finish(prev);
+      return FPV_FAILURE(fpvhip_last_error(ctx_));
+    }
     std::atomic<size_t> next(0);
-    std::atomic<bool> good(true);
     auto work = [&]() {
       for (;;) {
         size_t i = next.fetch_add(1);
         if (i >= count) return;
-        if (!Unpack(ins[first + i], sizes[first + i], (uint32_t)s, (uint32_t)i, &flags[i]))
-          good = false;
+        good[i] = Unpack(ins[first + i], sizes[first + i], (uint32_t)s, (uint32_t)i, &flags[i]);
       }
     };
     const size_t nt = std::min(threads, count);
@@ -212,20 +217,25 @@ bool InverseEngine::DecodeBatch(const uint8_t* const* ins, const size_t* sizes, 
     for (size_t t = 1; t < nt; t++) pool.emplace_back(work);
     work();
     for (auto& t : pool) t.join();
-    if (!good) {
+    size_t usable = 0;  // images in front of the first failure
+    while (usable < count && good[usable]) usable++;
+    if (usable > 0 && fpvhip_inverse_submit(ctx_, (uint32_t)s, (uint32_t)usable, flags.data())) {
       Release(s);
-      ok = false;
-      break;
-    }
-    if (fpvhip_inverse_submit(ctx_, (uint32_t)s, (uint32_t)count, flags.data())) {
-      Release(s);
-      ok = FPV_FAILURE(fpvhip_last_error(ctx_));
-      break;
+      finish(prev);
+      return FPV_FAILURE(fpvhip_last_error(ctx_));
     }
     finish(prev);
-    prev.slot = s;
-    prev.first = first;
-    prev.count = count;
+    if (usable > 0) {
+      prev.slot = s;
+      prev.first = first;
+      prev.count = usable;
+    } else {
+      Release(s);
+    }
+    if (usable < count) {  // deliver what precedes the failure, then stop
+      finish(prev);
+      return false;
+    }
   }
   finish(prev);
   return ok;
@@ -254,7 +264,11 @@ struct StreamingDecoder::State {
   size_t xs = 0, ys = 0;
   bool has_header = false;
   std::vector<uint8_t> carry;
-  std::shared_ptr<InverseEngine> engine;
+  std::shared_ptr<InverseEngine> engine;  // one image per GPU call (the usual block-wise feed)
+  // Calls that bring several complete frame chunks at once (whole files, large
+  // blocks) go through GPU batches with threaded Brotli; created on first need.
+  std::shared_ptr<InverseEngine> batch_engine;
+  std::vector<uint16_t> delta16;
 };
 
 // cc:866-956
@@ -293,6 +307,7 @@ void StreamingDecoder::Decode(
       if (!s.engine->Decode(in + pos + 5, dsz - 5, &px, &slot))
         FPV_FAIL_CB("decompressing delta frame failed");
       const bool set = s.engine->SetDelta(px);
+      if (set) s.delta16.assign(px, px + s.xs * s.ys);
       s.engine->Release(slot);
       if (!set) FPV_FAIL_CB("decompressing delta frame failed");
       pos += dsz;
@@ -302,22 +317,49 @@ void StreamingDecoder::Decode(
     }
   }
 
-  while (s.has_header) {  // frames (cc:914-936)
-    if (pos + 9 > insize) break;
-    const size_t fsz = Load32(in + pos);
-    const uint8_t flag = in[pos + 4];
-    if (flag == 2) break;  // frame index: end of frames
-    if (flag != 0) FPV_FAIL_CB("not a standard frame");
-    if (pos + fsz > insize) break;
-    const size_t psz = Load32(in + pos + 5);
-    if (fsz < 9 || psz > fsz - 9) FPV_FAIL_CB("preview size too large");
-    const uint16_t* px = nullptr;
-    int slot = -1;
-    const bool ok = s.engine->Decode(in + pos + 9 + psz, fsz - psz - 9, &px, &slot);
-    pos += fsz;
-    if (!ok) FPV_FAIL_CB("decompressing frame failed");
-    callback(true, const_cast<uint16_t*>(px), s.xs, s.ys, payload);
-    s.engine->Release(slot);
+  if (s.has_header) {  // frames (cc:914-936)
+    // Every complete frame chunk that is available now.  A malformed chunk ends
+    // the scan; its error is reported after the frames in front of it, as the
+    // reference's sequential loop would.
+    std::vector<const uint8_t*> mains;
+    std::vector<size_t> sizes;
+    const char* scan_error = nullptr;
+    size_t scan = pos;
+    while (scan + 9 <= insize) {
+      const size_t fsz = Load32(in + scan);
+      const uint8_t flag = in[scan + 4];
+      if (flag == 2) break;  // frame index: end of frames
+      if (flag != 0) { scan_error = "not a standard frame"; break; }
+      if (scan + fsz > insize) break;
+      const size_t psz = Load32(in + scan + 5);
+      if (fsz < 9 || psz > fsz - 9) { scan_error = "preview size too large"; break; }
+      mains.push_back(in + scan + 9 + psz);
+      sizes.push_back(fsz - psz - 9);
+      scan += fsz;
+    }
+    if (mains.size() == 1) {
+      const uint16_t* px = nullptr;
+      int slot = -1;
+      if (!s.engine->Decode(mains[0], sizes[0], &px, &slot)) FPV_FAIL_CB("decompressing frame failed");
+      callback(true, const_cast<uint16_t*>(px), s.xs, s.ys, payload);
+      s.engine->Release(slot);
+    } else if (mains.size() > 1) {
+      if (!s.batch_engine) {
+        const uint32_t batch = (uint32_t)std::min<size_t>(DecodeBatchFrames(s.xs * s.ys), 16);
+        s.batch_engine = InverseEngine::Create(s.xs, s.ys, batch, 2, DecoderDevice());
+        if (!s.batch_engine || !s.batch_engine->SetDelta(s.delta16.data())) FPV_FAIL_CB("no GPU decoder");
+      }
+      const size_t threads = std::min<size_t>(
+          EnvSize("FPV_DECODE_THREADS", std::max(1u, std::min(8u, std::thread::hardware_concurrency()))),
+          mains.size());
+      const bool ok = s.batch_engine->DecodeBatch(
+          mains.data(), sizes.data(), mains.size(),
+          [&](size_t, const uint16_t* px) { callback(true, const_cast<uint16_t*>(px), s.xs, s.ys, payload); },
+          threads);
+      if (!ok) FPV_FAIL_CB("decompressing frame failed");
+    }
+    pos = scan;
+    if (scan_error) FPV_FAIL_CB(scan_error);
   }
 
   // Keep what was not consumed (cc:938-953).
@@ -420,7 +462,10 @@ bool RandomAccessDecoder::DecodeFrames(const size_t* indices, size_t count,
   std::vector<size_t> sizes(count);
   for (size_t i = 0; i < count; i++)
     if (!FindMain(data_, size_, frame_offsets_, indices[i], &ins[i], &sizes[i])) return false;
-  return state_->engine->DecodeBatch(ins.data(), sizes.data(), count, out, threads);
+  const size_t bytes = xsize_ * ysize_ * 2;
+  return state_->engine->DecodeBatch(
+      ins.data(), sizes.data(), count,
+      [&](size_t i, const uint16_t* px) { memcpy(out[i], px, bytes); }, threads);
 }
 
 // cc:1038-1070

@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include <condition_variable>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <vector>
@@ -68,10 +69,16 @@ class InverseEngine {
   bool Decode(const uint8_t* in, size_t size, const uint16_t** frame, int* slot);
   void Release(int slot);
 
-  // Many images in GPU batches; outs[i] receives image i.  Brotli decoding of a
-  // batch is spread over `threads` host threads.
+  // Many images in GPU batches, Brotli decoding of a batch spread over
+  // `threads` host threads, the GPU inverting one batch while the host threads
+  // unpack the next.  sink(i, pixels) is called once per image, in order, from
+  // the calling thread; `pixels` is valid during the call only.  Images are
+  // delivered up to (not including) the first one that fails, then false is
+  // returned -- the order DecompressImage failures surface in the reference's
+  // sequential loops (cc:914-936).
+  typedef std::function<void(size_t index, const uint16_t* pixels)> Sink;
   bool DecodeBatch(const uint8_t* const* ins, const size_t* sizes, size_t n,
-                   uint16_t* const* outs, size_t threads);
+                   const Sink& sink, size_t threads);
 
  private:
   InverseEngine() {}

@@ -41,7 +41,8 @@ size_t fpvc_encode_stream(const uint16_t *frames, size_t nframes,
 long fpvc_decode_stream(const uint8_t *data, size_t size, uint16_t *frames_out,
                         size_t cap_frames, uint8_t *previews_out, int batched,
                         size_t threads);
-/* StreamingDecoder (h:37-57) fed in pieces of `block` bytes. */
+/* StreamingDecoder (h:37-57) fed in pieces of `block` bytes (0 = everything in one
+ * call).  Returns the frame count, or -(1 + frames delivered before the failure). */
 long fpvc_stream_decode(const uint8_t *data, size_t size, size_t block,
                         uint16_t *frames_out, size_t cap_frames);
 /* Stream header peek: 0 on success. */

@@ -75,3 +75,24 @@ def test_decoders_accept_odd_sizes(codec, oracle, xs, ys):
     if xs >= 4 and ys >= 4:
         _, pv = codec.decode_stream(stream, with_previews=True)
         assert pv.shape == (4, ys // 4, xs // 4)
+
+
+def test_streaming_decoder_batched_calls(codec, synth):
+    """StreamingDecoder fed whole files or large blocks takes the GPU-batch path
+    (several frames per inverse launch, threaded Brotli): same pixels and order
+    as the block-wise feed, at the BASELINE frame size."""
+    fr = synth.plasma_frames(20, 1280, 800, bits=12, seed=7)
+    fpv = codec.encode_stream(fr, fr[0], 1280, 800, 4, False, threads=8)
+    want = fr << 4
+    for block in (0, fpv.size // 3 + 7, 1 << 20):
+        assert np.array_equal(codec.stream_decode(fpv, 1280, 800, 20, block=block), want), block
+    # a corrupt frame inside a batch: everything in front of it is delivered first
+    bad = fpv.copy()
+    foot = bad[-(5 + 8 * 20 + 8):]
+    offs = np.frombuffer(foot[5:5 + 8 * 20].tobytes(), "<u8").astype(np.int64)
+    psz = int(np.frombuffer(bad[offs[11] + 5:offs[11] + 9].tobytes(), "<u4")[0])
+    main = int(offs[11]) + 9 + psz
+    bad[main + 1:main + 64] ^= 0x5A
+    with pytest.raises(RuntimeError) as ei:
+        codec.stream_decode(bad, 1280, 800, 20, block=0)
+    assert np.array_equal(ei.value.delivered, want[:11])

@@ -112,6 +112,42 @@ def test_corrupt_streams_fail_cleanly(codec, capfd):
     assert codec.stream_decode(good[:good.size // 2], 64, 48, 3, block=777).shape[0] < 3
 
 
+def test_streaming_decoder_whole_file_and_large_blocks(codec, synth):
+    """Calls that carry several complete frames go through the batched path
+    (threaded Brotli, GPU batches); results and order must equal the
+    block-by-block feed, for every way of cutting the stream."""
+    fr = synth.noise_frames(37, 64, 48, seed=11)
+    fr[5:20] >>= 6                                   # a run of CG-friendly frames
+    fpv = codec.encode_stream(fr, fr[0], 64, 48, threads=3)
+    for block in (0, fpv.size // 2 + 1, fpv.size // 3, 20000, 6500, 64):
+        assert np.array_equal(codec.stream_decode(fpv, 64, 48, 37, block=block), fr), block
+
+
+def test_streaming_decoder_failure_order_in_batches(codec, synth, capfd):
+    """A corrupt frame in the middle of a multi-frame call: the frames in front
+    of it are delivered, in order, then ok=false -- as the reference's sequential
+    loop does (cc:914-936)."""
+    fr = synth.noise_frames(12, 64, 48, seed=12)
+    fpv = codec.encode_stream(fr, fr[0], 64, 48, threads=2).copy()
+    n = 12
+    foot = fpv[-(5 + 8 * n + 8):]
+    offs = np.frombuffer(foot[5:5 + 8 * n].tobytes(), "<u8").astype(np.int64)
+    k = 7
+    psz = int(np.frombuffer(fpv[offs[k] + 5:offs[k] + 9].tobytes(), "<u4")[0])
+    main = int(offs[k]) + 9 + psz
+    fpv[main + 1:main + 40] ^= 0xA5                  # inside frame 7's Brotli streams
+    for block in (0, 30000):
+        with pytest.raises(RuntimeError) as ei:
+            codec.stream_decode(fpv, 64, 48, n, block=block)
+        assert np.array_equal(ei.value.delivered, fr[:k]), block
+    bad = codec.encode_stream(fr, fr[0], 64, 48, threads=2).copy()
+    bad[offs[9] + 4] = 3                             # chunk type of frame 9: not a standard frame
+    with pytest.raises(RuntimeError) as ei:
+        codec.stream_decode(bad, 64, 48, n, block=0)
+    assert np.array_equal(ei.value.delivered, fr[:9])
+    capfd.readouterr()
+
+
 def test_unextract_matches_oracle(codec, oracle, synth):
     img = synth.noise_frames(1, 64, 48, seed=8)[0]
     for shift, be in ((0, False), (4, False), (4, True), (8, True)):

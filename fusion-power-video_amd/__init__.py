@@ -215,9 +215,11 @@ class Predictor:
         return (ms, list(km)) if per_kernel else ms
 
     def inverse_pass_stats(self, reset=True):
-        """(supersteps, passes) of the speculative inverse kernel since the last reset."""
-        out = (ctypes.c_uint32 * 2)()
+        """(supersteps, passes) of the speculative inverse kernel since the last reset;
+        `self.last_pass_extremes` = (most passes on one frame, most on one superstep)."""
+        out = (ctypes.c_uint32 * 4)()
         self._check(self.lib.fpvhip_inverse_pass_stats(self.ctx, out, int(reset)), "inverse_pass_stats")
+        self.last_pass_extremes = (int(out[2]), int(out[3]))
         return int(out[0]), int(out[1])
 
     def time_inverse(self, high, low, flags, out, iters):

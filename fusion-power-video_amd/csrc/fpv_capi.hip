@@ -505,7 +505,7 @@ int fpvhip_inverse_pass_stats(fpvhip_ctx* c, uint32_t* out, int reset) {
   if (!c || !out) return fail(c, "bad arguments");
   HIPOK(c, hipSetDevice(c->device));
   HIPOK(c, hipDeviceSynchronize());
-  HIPOK(c, hipMemcpy(out, c->d_inv_diag, 8, hipMemcpyDeviceToHost));
+  HIPOK(c, hipMemcpy(out, c->d_inv_diag, 16, hipMemcpyDeviceToHost));
   if (reset) HIPOK(c, hipMemset(c->d_inv_diag, 0, 16));
   return 0;
 }

@@ -1395,17 +1395,53 @@ __global__ __launch_bounds__(64) void k_inverse_spec(
     *reinterpret_cast<uint2*>(outp + i) = o;
   };
 
-  if (!use_cg) {  // no chain at all
-    for (uint32_t o = lane * 16; o < npix; o += 1024) {
-      const uint32_t nq = min(4u, (npix - o) >> 2);
-      for (uint32_t q = 0; q < nq; q++) {
-        const uint32_t i = o + 4 * q;
-        emit4(i, *reinterpret_cast<const uint32_t*>(hp + i),
-              no_low ? 0u : *reinterpret_cast<const uint32_t*>(lp + i),
-              use_delta ? *reinterpret_cast<const uint32_t*>(dhigh + i) : 0u,
-              use_delta ? *reinterpret_cast<const uint32_t*>(dlow + i) : 0u);
+  if (!use_cg) {
+    // No chain at all: delta^-1 + recombine.  The frame still belongs to this one
+    // wave, so the loads of 4 steps (4096 pixels) are issued back to back before
+    // anything is consumed (16 KiB in flight per wave), which
+    // keeps such a frame well below the time of a clamped-gradient frame.
+    constexpr int U = 4;
+    uint32_t base = 0;
+    for (; base + U * 1024 <= npix; base += U * 1024) {
+      uint4 h[U], l[U], dh[U], dl[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) h[u] = *reinterpret_cast<const uint4*>(hp + base + u * 1024 + lane * 16);
+      if (!no_low) {
+#pragma unroll
+        for (int u = 0; u < U; u++) l[u] = *reinterpret_cast<const uint4*>(lp + base + u * 1024 + lane * 16);
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; u++) l[u] = make_uint4(0, 0, 0, 0);
+      }
+      if (use_delta) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          dh[u] = *reinterpret_cast<const uint4*>(dhigh + base + u * 1024 + lane * 16);
+          dl[u] = *reinterpret_cast<const uint4*>(dlow + base + u * 1024 + lane * 16);
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; u++) dh[u] = dl[u] = make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const uint32_t hh[4] = {add4(h[u].x, dh[u].x), add4(h[u].y, dh[u].y), add4(h[u].z, dh[u].z), add4(h[u].w, dh[u].w)};
+        const uint32_t ll[4] = {add4(l[u].x, dl[u].x), add4(l[u].y, dl[u].y), add4(l[u].z, dl[u].z), add4(l[u].w, dl[u].w)};
+        uint4 a, b2;
+        a.x = __builtin_amdgcn_perm(hh[0], ll[0], 0x05010400u); a.y = __builtin_amdgcn_perm(hh[0], ll[0], 0x07030602u);
+        a.z = __builtin_amdgcn_perm(hh[1], ll[1], 0x05010400u); a.w = __builtin_amdgcn_perm(hh[1], ll[1], 0x07030602u);
+        b2.x = __builtin_amdgcn_perm(hh[2], ll[2], 0x05010400u); b2.y = __builtin_amdgcn_perm(hh[2], ll[2], 0x07030602u);
+        b2.z = __builtin_amdgcn_perm(hh[3], ll[3], 0x05010400u); b2.w = __builtin_amdgcn_perm(hh[3], ll[3], 0x07030602u);
+        uint16_t* op = outp + base + u * 1024 + lane * 16;
+        *reinterpret_cast<uint4*>(op) = a;
+        *reinterpret_cast<uint4*>(op + 8) = b2;
       }
     }
+    for (uint32_t i = base + lane * 4; i < npix; i += 256)  // tail: fewer than 4096 pixels
+      emit4(i, *reinterpret_cast<const uint32_t*>(hp + i),
+            no_low ? 0u : *reinterpret_cast<const uint32_t*>(lp + i),
+            use_delta ? *reinterpret_cast<const uint32_t*>(dhigh + i) : 0u,
+            use_delta ? *reinterpret_cast<const uint32_t*>(dlow + i) : 0u);
     return;
   }
 
@@ -1452,7 +1488,7 @@ __global__ __launch_bounds__(64) void k_inverse_spec(
     }
   };
   fetch_r(head, rq);
-  uint32_t npass = 0;
+  uint32_t npass = 0, maxpass = 0;
 
   auto superstep = [&](uint32_t s0, auto full_tag) {
     constexpr bool FULL = decltype(full_tag)::value;
@@ -1494,27 +1530,26 @@ __global__ __launch_bounds__(64) void k_inverse_spec(
     }
     fetch_r(s0 + S, rq);  // next superstep's residuals (rq was consumed above)
 
-    // pass 1: every lane from its guess (lane 0 from the known value)
+    // Passes: the first one runs every lane from its guess (lane 0 from the known
+    // value), the following ones only the lanes whose input turned out wrong.  ONE
+    // copy of the chain code serves all passes, so X[] stays in fixed registers.
     uint32_t in = lane == 0 ? w_prev : guess;
-    {
-      uint32_t w = in;
-#pragma unroll
-      for (int k = 0; k < K; k++) X[k] = w = inv_px(N[k], w, D[k], R[k]);
-    }
-    npass++;
+    bool run = true;
+    const uint32_t npass0 = npass;
     for (;;) {
-      uint32_t pred = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)X[K - 1], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-      if (lane == 0) pred = w_prev;
-      const bool bad = active && pred != in;
-      if (!__builtin_amdgcn_ballot_w64(bad)) break;
-      npass++;
-      if (bad) {
-        in = pred;
+      if (run) {
         uint32_t w = in;
 #pragma unroll
         for (int k = 0; k < K; k++) X[k] = w = inv_px(N[k], w, D[k], R[k]);
       }
+      npass++;
+      uint32_t pred = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)X[K - 1], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+      if (lane == 0) pred = w_prev;
+      run = active && pred != in;
+      if (!__builtin_amdgcn_ballot_w64(run)) break;
+      in = pred;  // lanes that do not rerun have pred == in already
     }
+    maxpass = max(maxpass, npass - npass0);
     w_prev = (uint32_t)__builtin_amdgcn_readlane((int)X[K - 1], 63);
 
     // reconstructed bytes into the ring (north of the next row, source of the output phase)
@@ -1547,6 +1582,8 @@ __global__ __launch_bounds__(64) void k_inverse_spec(
   if (pass_count && lane == 0) {  // diagnostics: supersteps and passes (bench / tests)
     atomicAdd(&pass_count[0], (npix - head + S - 1) / S);
     atomicAdd(&pass_count[1], npass);
+    atomicMax(&pass_count[2], npass);      // the slowest frame bounds a launch with one wave per SIMD
+    atomicMax(&pass_count[3], maxpass);    // longest verification chain seen in one superstep
   }
 }
 

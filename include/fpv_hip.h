@@ -190,10 +190,12 @@ double fpvhip_time_predict_device(fpvhip_ctx *ctx, const void *d_frames,
 /* Diagnostics: the first n (<= 64) dwords of the device-entry-point workspace's
  * counter block after the last predict_device (list sizes, votes, task counter). */
 int fpvhip_debug_counters(fpvhip_ctx *ctx, uint32_t *out, uint32_t n);
-/* Diagnostics of the speculative inverse kernel (cc:326-333 replacement): out[0] =
- * supersteps, out[1] = chain passes executed by all inverse launches of this
- * context since the last reset (passes / supersteps = average passes; 1 = every
- * guess was right, 64 = fully serial).  Synchronises the device. */
+/* Diagnostics of the speculative inverse kernel (cc:326-333 replacement), four
+ * dwords: out[0] = supersteps, out[1] = chain passes executed by all inverse
+ * launches of this context since the last reset (passes / supersteps = average
+ * passes; 1 = every guess was right, 64 = fully serial), out[2] = most passes
+ * spent on one frame, out[3] = most passes spent on one superstep.
+ * Synchronises the device. */
 int fpvhip_inverse_pass_stats(fpvhip_ctx *ctx, uint32_t *out, int reset);
 /* Bench only: `iters` plain 16-B-per-lane device copies of `bytes` bytes on
  * `stream`; returns elapsed ms.  The measured HBM ceiling kernels are compared with. */

@@ -69,20 +69,28 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=NFRAMES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (RCCL, one GPU per rank) or gloo (rehearsal)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal on a box with fewer GPUs than ranks: rank r uses GPU r %% device_count")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    if args.share_gpu:
+        local_rank %= max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     if world > 1:
+        # The ranks never exchange frame data: the process group only carries the
+        # barrier and the max-over-ranks of the elapsed time.
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend)
 
     pkg = load_package()
     synth = importlib.import_module("fpv_amd.synth")
@@ -112,7 +120,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -174,10 +182,13 @@ def main():
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):
             try:
-                t = json.load(open(tf)).get(names[dom])
+                tj = json.load(open(tf))
+                t = tj.get(names[dom])
                 if t and n == NFRAMES:   # PMC bytes per launch of the same 1000-frame workload
                     res["roofline"]["traffic"] = t["bytes_per_launch"]
                     res["roofline"]["traffic_source"] = t["source"]
+                if inv is not None and n == NFRAMES and tj.get(inv["kernel"]):
+                    res["inverse"]["traffic"] = tj[inv["kernel"]]["bytes_per_launch"]
             except Exception:
                 pass
         if world == 1 and not args.no_cpu_baseline:

@@ -1162,6 +1162,9 @@ __global__ __launch_bounds__(64) void k_inverse(
 // chain redundantly on wave-uniform data; the other phases are data parallel.
 constexpr uint32_t kInvC = 256;
 constexpr uint32_t kSpecMaxK4 = 6;  // speculative inverse: at most 24 pixels per lane and superstep
+// speculative inverse: passes of a superstep during which run-of-shift-lanes proposals are made;
+// afterwards the plain rule (input := previous lane's output) guarantees the end within 64 passes
+constexpr uint32_t kScanAfter = 4, kScanUntil = 28;  // measured: the unrolled 4-pass loop is the fastest common case
 
 // One-wave workgroups: LDS hand-offs between the phases only need this wave's
 // own LDS operations to have completed.  __syncthreads() would also drain the
@@ -1533,10 +1536,21 @@ __global__ __launch_bounds__(64) void k_inverse_spec(
     // Passes: the first one runs every lane from its guess (lane 0 from the known
     // value), the following ones only the lanes whose input turned out wrong.  ONE
     // copy of the chain code serves all passes, so X[] stays in fixed registers.
+    //
+    // Long correction chains come from segments whose north pixels are all equal
+    // (d == 0 everywhere): there the predictor is the identity, the segment maps
+    // its input w to w + sum(r) for EVERY w, and a wrong guess is never forgotten.
+    // When a superstep is still wrong after kScanAfter passes, such "shift" lanes
+    // are detected and the inputs of whole runs of them are proposed at once by a
+    // prefix scan over the lanes (shift lanes add their sum, other lanes contribute
+    // their current output).  A proposal is only ever a proposal: the loop still
+    // ends on the same check (every input equals the previous lane's actual
+    // output), so exactness does not depend on it.
     uint32_t in = lane == 0 ? w_prev : guess;
     bool run = true;
     const uint32_t npass0 = npass;
-    for (;;) {
+    bool settled = false;
+    for (uint32_t round = 0; round < kScanAfter; round++) {  // the common case ends in here
       if (run) {
         uint32_t w = in;
 #pragma unroll
@@ -1546,8 +1560,47 @@ __global__ __launch_bounds__(64) void k_inverse_spec(
       uint32_t pred = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)X[K - 1], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
       if (lane == 0) pred = w_prev;
       run = active && pred != in;
-      if (!__builtin_amdgcn_ballot_w64(run)) break;
+      if (!__builtin_amdgcn_ballot_w64(run)) { settled = true; break; }
       in = pred;  // lanes that do not rerun have pred == in already
+    }
+    if (__builtin_expect(!settled, 0)) {
+      // Still wrong after kScanAfter passes: a long correction chain.  Its own copy
+      // of the pass loop, so that nothing of it burdens the loop above.
+      uint32_t all, ord = 0, sum = 0;
+      asm volatile("v_mov_b32 %0, -1" : "=v"(all));  // keeps the compiler from hoisting the 2K ops below
+#pragma unroll
+      for (int k = 0; k < K; k++) { ord = max(ord, D[k] & all); sum += R[k] & all; }
+      const bool is_shift = ord == 0 && lane != 0;  // lane 0 is final after the first pass: a constant
+      const uint32_t ssum = sum & 0xffffu;
+      for (;;) {
+        if (run) {
+          uint32_t w = in;
+#pragma unroll
+          for (int k = 0; k < K; k++) X[k] = w = inv_px(N[k], w, D[k], R[k]);
+        }
+        npass++;
+        uint32_t pred = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)X[K - 1], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+        if (lane == 0) pred = w_prev;
+        const bool bad = active && pred != in;
+        if (!__builtin_amdgcn_ballot_w64(bad)) break;
+        uint32_t next_in = pred;
+        if (npass - npass0 < kScanUntil) {  // wave-uniform
+          // inclusive scan of the lanes' functions: CONST(c) or SHIFT(s); lane 0 is CONST
+          uint32_t isc = is_shift ? 0u : 1u, v = is_shift ? ssum : X[K - 1];
+#pragma unroll
+          for (int dlt = 1; dlt < 64; dlt <<= 1) {
+            const uint32_t isc_l = __shfl_up(isc, dlt, 64), v_l = __shfl_up(v, dlt, 64);
+            if (lane >= (uint32_t)dlt && !isc) {
+              v = (v + v_l) & 0xffffu;
+              isc = isc_l;
+            }
+          }
+          next_in = __shfl_up(v, 1, 64);  // the consistent output of lane j-1
+          if (lane == 0) next_in = w_prev;
+        }
+        run = active && next_in != in;  // bad somewhere implies run somewhere
+        in = next_in;
+      }
     }
     maxpass = max(maxpass, npass - npass0);
     w_prev = (uint32_t)__builtin_amdgcn_readlane((int)X[K - 1], 63);

@@ -120,3 +120,49 @@ def test_pass_counts_separate_easy_from_hard(fpv, synth, oracle):
     steps2, passes2 = p.inverse_pass_stats()
     assert steps2 > 0 and passes / steps < passes2 / steps2 <= 64, (steps2, passes2)
     p.close()
+
+
+def _cg_residuals(x, xs):
+    """Forward clamped gradient (cc:566-572) of a flat plane with numpy: residuals
+    from ORIGINAL neighbours, the first xs + 1 bytes literal."""
+    x = x.astype(np.int32).reshape(-1)
+    r = x.copy()
+    i = np.arange(xs + 1, x.size)
+    n, w, nw = x[i - xs], x[i - 1], x[i - xs - 1]
+    g = n + w - nw
+    pred = np.maximum(np.minimum(n, w), np.minimum(np.maximum(n, w), g))
+    r[i] = (x[i] - pred) & 0xff
+    return r.astype(np.uint8)
+
+
+def test_adversarial_flat_rows_cascade(fpv, oracle):
+    """The hardest input for the guesses: every image row constant, a different
+    constant per row.  The predictor is the identity along such a row (a wrong
+    guess is never forgotten) and the pixel above the west neighbour is always the
+    wrong guess, so with the plain rule corrections travel one lane per pass (64
+    passes per superstep).  The kernel recognises such identity ("shift") segments
+    after three passes and proposes the inputs of whole runs of them with a prefix
+    scan over the lanes: a handful of passes, and exact either way."""
+    import torch
+    xs, ys = 1280, 40
+    rng = np.random.default_rng(99)
+    rows = rng.integers(0, 256, ys).astype(np.uint8)
+    img = np.repeat(rows[:, None], xs, axis=1)
+    img2 = img.copy()
+    img2[:, xs // 2:] = (img2[:, xs // 2:].astype(np.int32) * 7 + 13).astype(np.uint8)  # a step in every row
+    high = np.stack([_cg_residuals(img, xs).reshape(ys, xs), _cg_residuals(img2, xs).reshape(ys, xs)])
+    low = np.zeros_like(high)
+    p = fpv.Predictor(xs, ys, 0, False, max_batch=2)
+    p.inverse_pass_stats(reset=True)
+    rec = p.inverse(torch.from_numpy(high).cuda(), torch.from_numpy(low).cuda(),
+                    torch.tensor([6, 6], dtype=torch.uint8).cuda())     # CG, no low plane
+    torch.cuda.synchronize()
+    steps, passes = p.inverse_pass_stats()
+    rec = rec.cpu().view(torch.int16).numpy().view(np.uint16)
+    assert np.array_equal(rec[0] >> 8, img) and np.array_equal(rec[1] >> 8, img2)
+    for k in range(2):
+        exp = oracle.inverse(high[k].reshape(-1), None, None, xs, ys, 6)
+        assert np.array_equal(rec[k].reshape(-1), np.asarray(exp).reshape(-1))
+    assert passes / steps < 10, (steps, passes)
+    assert p.last_pass_extremes[1] <= 64
+    p.close()

@@ -22,6 +22,7 @@ thread_local char g_err[256] = "";
 struct Slot {
   hipStream_t stream = nullptr;
   hipEvent_t done = nullptr;
+  hipEvent_t begin = nullptr;  // recorded in front of a batch's first transfer (stage timing)
   // pinned host
   uint16_t* h_pix = nullptr;  // [B][npix]  forward input / inverse output
   uint8_t* h_high = nullptr;  // [B][npix]  forward output / inverse input
@@ -84,7 +85,8 @@ int fail(fpvhip_ctx* c, const char* fmt, ...) {
 int alloc_slot(fpvhip_ctx* c, Slot* s) {
   const size_t B = c->max_batch, np = c->g.npix, nv = c->g.npv;
   HIPOK(c, hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
-  HIPOK(c, hipEventCreateWithFlags(&s->done, hipEventDisableTiming));
+  HIPOK(c, hipEventCreate(&s->done));
+  HIPOK(c, hipEventCreate(&s->begin));
   HIPOK(c, hipHostMalloc(reinterpret_cast<void**>(&s->h_pix), B * np * 2, hipHostMallocDefault));
   HIPOK(c, hipHostMalloc(reinterpret_cast<void**>(&s->h_high), B * np, hipHostMallocDefault));
   HIPOK(c, hipHostMalloc(reinterpret_cast<void**>(&s->h_low), B * np, hipHostMallocDefault));
@@ -111,6 +113,7 @@ void free_slot(Slot* s) {
   hipFree(s->d_pix); hipFree(s->d_high); hipFree(s->d_low);
   hipFree(s->d_pv); hipFree(s->d_flags); hipFree(s->d_ws);
   if (s->done) hipEventDestroy(s->done);
+  if (s->begin) hipEventDestroy(s->begin);
   if (s->stream) hipStreamDestroy(s->stream);
   *s = Slot();
 }
@@ -309,6 +312,7 @@ static int predict_submit_impl(fpvhip_ctx* c, uint32_t slot, uint32_t nframes, i
   Slot& s = c->slots[slot];
   const size_t np = c->g.npix, nv = c->g.npv;
   HIPOK(c, hipSetDevice(c->device));
+  HIPOK(c, hipEventRecord(s.begin, s.stream));
   if (from_planes) {  // planes staged in h_high / h_low -> pixels on the device
     HIPOK(c, hipMemcpyAsync(s.d_high, s.h_high, nframes * np, hipMemcpyHostToDevice, s.stream));
     HIPOK(c, hipMemcpyAsync(s.d_low, s.h_low, nframes * np, hipMemcpyHostToDevice, s.stream));
@@ -378,6 +382,7 @@ static int inverse_submit_impl(fpvhip_ctx* c, uint32_t slot, uint32_t nframes,
     if ((flags[k] & 1) && !c->have_delta) return fail(c, "delta frame not given");  // cc:310
   }
   HIPOK(c, hipSetDevice(c->device));
+  HIPOK(c, hipEventRecord(s.begin, s.stream));
   HIPOK(c, hipMemcpyAsync(s.d_high, s.h_high, nframes * np, hipMemcpyHostToDevice, s.stream));
   if (any_low)
     HIPOK(c, hipMemcpyAsync(s.d_low, s.h_low, nframes * np, hipMemcpyHostToDevice, s.stream));
@@ -499,6 +504,13 @@ int fpvhip_debug_counters(fpvhip_ctx* c, uint32_t* out, uint32_t n) {
   HIPOK(c, hipDeviceSynchronize());
   HIPOK(c, hipMemcpy(out, c->ws.counters, n * 4, hipMemcpyDeviceToHost));
   return 0;
+}
+
+double fpvhip_slot_elapsed_ms(fpvhip_ctx* c, uint32_t slot) {
+  if (!c || slot >= c->slots.size() || !c->slots[slot].ready || c->slots[slot].pending) return -1.0;
+  float ms = -1.f;
+  if (hipEventElapsedTime(&ms, c->slots[slot].begin, c->slots[slot].done) != hipSuccess) return -1.0;
+  return ms;
 }
 
 int fpvhip_inverse_pass_stats(fpvhip_ctx* c, uint32_t* out, int reset) {

@@ -259,6 +259,15 @@ struct Encoder::Impl {
   std::thread dispatcher;
   std::vector<std::thread> workers;
 
+  // Stage statistics (FPV_STATS=1: one stderr line from Finish).  Times in ns.
+  const bool stats = getenv("FPV_STATS") != nullptr;
+  std::atomic<uint64_t> st_brotli_ns{0}, st_copy_ns{0}, st_gpu_wait_ns{0}, st_gpu_us{0}, st_batches{0};
+  std::chrono::steady_clock::time_point st_t0;
+  static uint64_t NowNs() {
+    return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(
+               std::chrono::steady_clock::now().time_since_epoch()).count();
+  }
+
   Impl(size_t threads, int s, bool be) : num_threads(threads), shift(s), big_endian(be) {
     if (threads == 0) {
       batch_promised = 1;
@@ -342,8 +351,15 @@ struct Encoder::Impl {
       Batch* b = gpu_q.front();
       gpu_q.pop_front();
       l.unlock();
+      const uint64_t tw = stats ? NowNs() : 0;
       CheckHip(fpvhip_predict_wait(ctxs[b->dev], b->slot, &b->high, &b->low, &b->pv, &b->flags),
                ctxs[b->dev], "fpvhip_predict_wait");
+      if (stats) {
+        st_gpu_wait_ns += NowNs() - tw;
+        const double ms = fpvhip_slot_elapsed_ms(ctxs[b->dev], b->slot);
+        if (ms > 0) st_gpu_us += (uint64_t)(ms * 1000.0);
+        st_batches++;
+      }
       l.lock();
       b->chunks.resize(b->n);
       b->done.assign(b->n, 0);
@@ -399,7 +415,9 @@ struct Encoder::Impl {
         Task t = copy_q.front();
         copy_q.pop_front();
         l.unlock();
+        const uint64_t tc = stats ? NowNs() : 0;
         memcpy(fpvhip_stage_in(ctxs[t.b->dev], t.b->slot, t.k), t.src, npix * 2);
+        if (stats) st_copy_ns += NowNs() - tc;
         l.lock();
         t.b->copied++;
         if (t.b->closed && t.b->copied == t.b->n) SubmitLocked(t.b);
@@ -413,7 +431,9 @@ struct Encoder::Impl {
       work_q.pop_front();
       l.unlock();
       std::vector<uint8_t> chunk;
+      const uint64_t tb = stats ? NowNs() : 0;
       CompressTask(t, &chunk);
+      if (stats) st_brotli_ns += NowNs() - tb;
       l.lock();
       t.b->chunks[t.k].swap(chunk);
       t.b->done[t.k] = 1;
@@ -464,6 +484,7 @@ void Encoder::Init(const uint16_t* delta_frame, size_t xsize, size_t ysize,
   const bool timing = getenv("FPV_TIMING") != nullptr;
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t_start = now();
+  s.st_t0 = std::chrono::steady_clock::now();
   s.xs = xsize;
   s.ys = ysize;
   s.npix = xsize * ysize;
@@ -570,6 +591,22 @@ void Encoder::Finish(Callback callback, void* payload) {
   s.ReleaseContexts();
   // frame index (cc:1185-1197)
   const size_t n = s.offsets.size();
+  if (s.stats && n > 0 && s.num_threads > 0) {
+    // Stage totals of the pipeline: the GPU stage is what the slots' streams spent
+    // (H2D + kernels + D2H, HIP events), Brotli and staging copies are summed over
+    // the worker threads.  With perfect overlap the wall time equals the largest of
+    // gpu / devices, (brotli + copies) / threads.
+    const double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - s.st_t0).count();
+    const double gpu = s.st_gpu_us / 1e3, brotli = s.st_brotli_ns / 1e6, copy = s.st_copy_ns / 1e6;
+    const double host_stage = (brotli + copy) / (double)s.num_threads, gpu_stage = gpu / (double)s.devices.size();
+    const double bound = std::max(host_stage, gpu_stage);
+    fprintf(stderr,
+            "fpv-mi355x: stats: %zu frames %zux%zu, wall %.1f ms (%.1f fps); GPU stage (H2D+kernels+D2H) %.1f ms in %llu "
+            "batches = %.3f ms/frame; Brotli %.1f ms + staging copies %.1f ms over %zu threads = %.3f ms/frame/thread; "
+            "dispatcher blocked on the GPU %.1f ms; overlap: max(stage)/wall = %.2f, sum(stages)/wall = %.2f\n",
+            n, s.xs, s.ys, wall, n / wall * 1e3, gpu, (unsigned long long)s.st_batches.load(), gpu / n, brotli, copy,
+            s.num_threads, (brotli + copy) / n, s.st_gpu_wait_ns / 1e6, bound / wall, (host_stage + gpu_stage) / wall);
+  }
   std::vector<uint8_t> out(5 + 8 * n + 8);
   Store32((uint32_t)out.size(), out.data());
   out[4] = 2;

@@ -9,7 +9,7 @@
 
 namespace fpvhip {
 
-// Number of 256-bin histograms kept per frame by the decision stage.
+// Number of 256-bin histograms taken per frame by the exact (redo) decision stage.
 //   0: raw high bytes at stride 15                     (delta decision, cc:526-531)
 //   1/2: a / a - CG at stride 31, delta NOT applied    (CG decision,    cc:554-562)
 //   3/4: the same with the delta planes subtracted
@@ -47,7 +47,6 @@ bool make_geom(uint32_t xs, uint32_t ys, int shift, int big_endian, Geom* g,
 bool make_geom_decoder(uint32_t xs, uint32_t ys, Geom* g, const char** why);
 
 struct FwdWorkspace {
-  uint32_t* hists;     // [nframes][kNumHists][256] exact histograms of redone frames
   uint32_t* anylow;    // [nframes]  OR of raw low bytes
   uint32_t* counters;  // |list A|, |list B|, votes[4]
   uint8_t* decision;   // [nframes]  bit0 delta, bit1 CG
@@ -56,7 +55,7 @@ struct FwdWorkspace {
   uint8_t* pv_raw;     // [nframes][npv] un-predicted preview
   uint16_t* partials;  // [nframes][tiles][3][256] per-tile histograms of the fused pass
   uint8_t* spec;       // speculated flags for the next batch
-  size_t zero_fixed;   // bytes in front of hists that every batch zeroes (counters, anylow)
+  size_t zero_fixed;   // leading bytes that every batch zeroes (counters, anylow)
 };
 size_t fwd_workspace_bytes(const Geom& g, uint32_t nframes);
 void carve_fwd_workspace(const Geom& g, uint32_t nframes, void* base,

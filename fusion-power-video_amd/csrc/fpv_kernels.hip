@@ -19,6 +19,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <mutex>
 #include <type_traits>
 
 namespace fpvhip {
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(kThreads) void k_split_decoded(
 //                  the true decision with the speculation; mis-speculated
 //                  frames go to list A (delta decision wrong: histograms of the
 //                  CG decision are void) or list B (only the CG decision wrong)
-//   k_stats_list / k_decide_list / k_apply_list
+//   k_redo_decide / k_apply_list
 //                  exact, non-speculative redo of the listed frames (normally
 //                  none: these launches exit at once)
 //   k_finish       preview clamped gradient, flags byte, next speculation
@@ -809,66 +810,94 @@ __device__ __forceinline__ uint64_t entropy_bins(uint32_t v, uint32_t* scratch) 
   return (uint64_t)1024 * s / sum;
 }
 
-// Workspace counters (u32): [0] |list A|, [1] |list B|, [2..5] votes per flags value.
+// Sum over the 64 lanes of a wave; every lane gets the result.
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// EstimateEntropy (cc:235-244) of one 256-bin histogram held by a wave, four
+// bins per lane.  Same integer arithmetic as entropy_bins.
+__device__ __forceinline__ uint64_t entropy_wave(const uint32_t v[4]) {
+  const uint32_t sum = wave_sum(v[0] + v[1] + v[2] + v[3]);
+  if (sum == 0) return 0;
+  const uint32_t lsum = 31 - __clz(sum);
+  uint32_t term = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) term += v[k] ? v[k] * (lsum - (31 - __clz(v[k]))) : 0;
+  return (uint64_t)1024 * wave_sum(term) / sum;
+}
+
+// Workspace counters (u32): [0] |list A|, [1] |list B|, [6] k_stream's task counter.
+// One WAVE per frame (four frames per workgroup): no barriers, the reductions are
+// wave shuffles, so all frames of a batch decide concurrently.
 __global__ __launch_bounds__(kThreads) void k_decide_spec(
     const uint16_t* __restrict__ partials, const uint8_t* __restrict__ spec_ptr,
     uint8_t* __restrict__ decision, uint32_t* __restrict__ counters,
-    uint32_t* __restrict__ list_a, uint32_t* __restrict__ list_b, Geom g, int with_delta) {
-  __shared__ uint32_t scratch[4];
-  const uint32_t frame = blockIdx.x, tid = threadIdx.x;
+    uint32_t* __restrict__ list_a, uint32_t* __restrict__ list_b, Geom g, int with_delta,
+    uint32_t nframes) {
+  const uint32_t frame = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (frame >= nframes) return;
   const uint32_t nparts = g.strips;
-  const uint16_t* ph = partials + (size_t)frame * nparts * (kHistFused * 256);
-  uint32_t v[kHistFused] = {0, 0, 0};
-#pragma unroll 8
+  const uint16_t* ph = partials + (size_t)frame * nparts * (kHistFused * 256) + lane * 4;
+  uint32_t v[kHistFused][4] = {};
+#pragma unroll 4
   for (uint32_t t = 0; t < nparts; t++) {
 #pragma unroll
-    for (int h = 0; h < kHistFused; h++) v[h] += ph[(t * kHistFused + h) * 256 + tid];
+    for (int h = 0; h < kHistFused; h++) {
+      const uint2 q = *reinterpret_cast<const uint2*>(ph + (t * kHistFused + h) * 256);  // 4 x u16
+      v[h][0] += q.x & 0xffffu; v[h][1] += q.x >> 16;
+      v[h][2] += q.y & 0xffffu; v[h][3] += q.y >> 16;
+    }
   }
   const uint32_t spec = *spec_ptr & (with_delta ? 3u : 2u);
   // cc:533: E(countd) < E(counta); countd has everything in bin 0, E(countd) == 0
-  const bool use_delta = with_delta && entropy_bins(v[0], scratch) > 0;
+  const bool use_delta = with_delta && entropy_wave(v[0]) > 0;
   if (use_delta != (bool)(spec & 1)) {
-    if (tid == 0) {
+    if (lane == 0) {
       decision[frame] = 0xff;
       list_a[atomicAdd(&counters[0], 1u)] = frame;
     }
     return;
   }
-  const uint64_t ea = entropy_bins(v[1], scratch);
-  const uint64_t eb = entropy_bins(v[2], scratch);
+  const uint64_t ea = entropy_wave(v[1]);
+  const uint64_t eb = entropy_wave(v[2]);
   const bool use_cg = eb < ea;  // cc:564
-  if (tid == 0) {
+  if (lane == 0) {
     const uint32_t dec = (use_delta ? 1u : 0u) | (use_cg ? 2u : 0u);
     decision[frame] = (uint8_t)dec;
-    atomicAdd(&counters[2 + dec], 1u);
     if (use_cg != (bool)(spec & 2)) list_b[atomicAdd(&counters[1], 1u)] = frame;
   }
 }
 
 // ---- exact fallback for mis-speculated frames (list driven, grid stride) ----
 
-// One thread per sample; all five histograms (both delta hypotheses).
+// Exact decisions of the frames whose delta decision was mis-speculated (list A;
+// normally empty, the launch exits at once): one workgroup per listed frame takes
+// all five histograms (both delta hypotheses) of the heuristics' samples in LDS,
+// evaluates EstimateEntropy and appends the frame to list B for the re-apply pass.
 template <bool SWAP>
-__global__ __launch_bounds__(kThreads) void k_stats_list(
+__global__ __launch_bounds__(kThreads) void k_redo_decide(
     const uint16_t* __restrict__ frames, const uint8_t* __restrict__ dhigh,
-    const uint32_t* __restrict__ counters, const uint32_t* __restrict__ list_a,
-    uint32_t* __restrict__ hists, Geom g, int with_delta) {
+    uint8_t* __restrict__ decision, uint32_t* __restrict__ counters,
+    const uint32_t* __restrict__ list_a, uint32_t* __restrict__ list_b, Geom g, int with_delta) {
   __shared__ uint32_t lh[kNumHists * 256];
-  const uint32_t items = counters[0] * g.stat_blocks;
-  for (uint32_t w = blockIdx.x; w < items; w += gridDim.x) {
-    const uint32_t frame = list_a[w / g.stat_blocks], sb = w % g.stat_blocks;
+  __shared__ uint32_t scratch[4];
+  const uint32_t na = counters[0];
+  for (uint32_t w = blockIdx.x; w < na; w += gridDim.x) {
+    const uint32_t frame = list_a[w];
     const uint16_t* img = frames + (size_t)frame * g.npix;
     for (int b = threadIdx.x; b < kNumHists * 256; b += kThreads) lh[b] = 0;
     __syncthreads();
-    const uint32_t stride = g.stat_blocks * kThreads, t0 = sb * kThreads + threadIdx.x;
     uint32_t h, l;
     if (with_delta) {  // cc:526-531
-      for (uint32_t k = t0; k < g.nd; k += stride) {
+      for (uint32_t k = threadIdx.x; k < g.nd; k += kThreads) {
         split1<SWAP>(img[15u * k], g.shift, &h, &l);
         atomicAdd(&lh[h], 1u);
       }
     }
-    for (uint32_t k = t0; k < g.ncg; k += stride) {  // cc:554-562
+    for (uint32_t k = threadIdx.x; k < g.ncg; k += kThreads) {  // cc:554-562
       const uint32_t i = g.xs + 1 + 31u * k;
       uint32_t x, n, ww, nw;
       split1<SWAP>(img[i], g.shift, &x, &l);
@@ -887,35 +916,16 @@ __global__ __launch_bounds__(kThreads) void k_stats_list(
       }
     }
     __syncthreads();
-    uint32_t* gh = hists + (size_t)frame * kNumHists * 256;
-    for (int b = threadIdx.x; b < kNumHists * 256; b += kThreads) {
-      const uint32_t v = lh[b];
-      if (v) atomicAdd(&gh[b], v);
-    }
-    __syncthreads();
-  }
-}
-
-__global__ __launch_bounds__(kThreads) void k_decide_list(
-    const uint32_t* __restrict__ hists, uint8_t* __restrict__ decision,
-    uint32_t* __restrict__ counters, const uint32_t* __restrict__ list_a,
-    uint32_t* __restrict__ list_b, int with_delta) {
-  __shared__ uint32_t scratch[4];
-  const uint32_t na = counters[0];
-  for (uint32_t w = blockIdx.x; w < na; w += gridDim.x) {
-    const uint32_t frame = list_a[w];
-    const uint32_t* gh = hists + (size_t)frame * kNumHists * 256;
-    const bool use_delta = with_delta && entropy_bins(gh[threadIdx.x], scratch) > 0;
-    const uint32_t* ha = gh + (use_delta ? 3 : 1) * 256;
+    const bool use_delta = with_delta && entropy_bins(lh[threadIdx.x], scratch) > 0;
+    const uint32_t* ha = lh + (use_delta ? 3 : 1) * 256;
     const uint64_t ea = entropy_bins(ha[threadIdx.x], scratch);
     const uint64_t eb = entropy_bins(ha[256 + threadIdx.x], scratch);
     const bool use_cg = eb < ea;
     if (threadIdx.x == 0) {
-      const uint32_t dec = (use_delta ? 1u : 0u) | (use_cg ? 2u : 0u);
-      decision[frame] = (uint8_t)dec;
-      atomicAdd(&counters[2 + dec], 1u);
+      decision[frame] = (uint8_t)((use_delta ? 1u : 0u) | (use_cg ? 2u : 0u));
       list_b[atomicAdd(&counters[1], 1u)] = frame;
     }
+    __syncthreads();
   }
 }
 
@@ -1022,12 +1032,25 @@ __global__ __launch_bounds__(kThreads) void k_finish(
       }
     }
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    flags[frame] = (uint8_t)(dec | (anylow[frame] ? 0 : 4));
-    if (frame == 0) {  // all decisions are final at this point (stream order)
+  if (blockIdx.x == 0 && threadIdx.x == 0) flags[frame] = (uint8_t)(dec | (anylow[frame] ? 0 : 4));
+  if (blockIdx.x == 0 && frame == 0) {
+    // Next batch's speculation = the most frequent decision of this one.  All
+    // decisions are final here (stream order).  Counted by this one workgroup from
+    // the decision bytes: a thousand frames voting with global atomics on one word
+    // cost the decision kernel ~12 us (same-address atomics serialise at ~12 ns).
+    __shared__ uint32_t votes[4];
+    if (threadIdx.x < 4) votes[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t mine[4] = {0, 0, 0, 0};
+    for (uint32_t f = threadIdx.x; f < gridDim.y; f += kThreads) mine[decision[f] & 3u]++;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (mine[k]) atomicAdd(&votes[k], mine[k]);
+    __syncthreads();
+    if (threadIdx.x == 0) {
       uint32_t best = 0;
       for (uint32_t k = 1; k < 4; k++)
-        if (counters[2 + k] > counters[2 + best]) best = k;
+        if (votes[k] > votes[best]) best = k;
       *spec_ptr = (uint8_t)best;
     }
   }
@@ -1646,6 +1669,20 @@ __global__ __launch_bounds__(64) void k_inverse_spec(
 
 static uint32_t round_up(uint32_t v, uint32_t a) { return (v + a - 1) / a * a; }
 
+// Function attributes (dynamic LDS above 64 KiB) are per device: runs `set` once
+// for the calling thread's current device, under a lock, so that in-process
+// multi-GPU sessions and concurrent first launches are safe.
+template <typename F>
+static void once_per_device(std::mutex& m, uint64_t& done_mask, F set) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  const uint64_t bit = 1ull << (dev & 63);
+  std::lock_guard<std::mutex> l(m);
+  if (done_mask & bit) return;
+  set();
+  done_mask |= bit;
+}
+
 // Speculative inverse: the largest supported segment length K = 4 * k4 with a
 // superstep of 64 * K pixels that fits into one image row (its north pixels must
 // lie in front of it).
@@ -1764,12 +1801,10 @@ bool make_geom_decoder(uint32_t xs, uint32_t ys, Geom* g, const char** why) {
   return true;
 }
 
-// Workspace layout: [counters | anylow | hists] are zeroed by ONE memset per
-// batch (hists only for the frames of the batch); the rest is fully written by
-// the kernels.  `spec` survives batches.
+// Workspace layout: [counters | anylow] are zeroed by ONE memset per batch; the
+// rest is fully written by the kernels.  `spec` survives batches.
 size_t fwd_workspace_bytes(const Geom& g, uint32_t max_frames) {
   size_t b = 256 + round_up(max_frames * 4, 256);                // counters, anylow
-  b += (size_t)max_frames * kNumHists * 256 * 4;                 // hists
   b += round_up(max_frames, 256);                                // decision
   b += 2 * (size_t)round_up(max_frames * 4, 256);                // list A, list B
   b += round_up((size_t)max_frames * g.npv, 256);                // pv_raw
@@ -1784,9 +1819,7 @@ void carve_fwd_workspace(const Geom& g, uint32_t max_frames, void* base,
   p += 256;
   ws->anylow = reinterpret_cast<uint32_t*>(p);
   p += round_up(max_frames * 4, 256);
-  ws->hists = reinterpret_cast<uint32_t*>(p);
   ws->zero_fixed = (size_t)(p - static_cast<uint8_t*>(base));
-  p += (size_t)max_frames * kNumHists * 256 * 4;
   ws->decision = p;
   p += round_up(max_frames, 256);
   ws->list_a = reinterpret_cast<uint32_t*>(p);
@@ -1850,7 +1883,7 @@ static hipError_t predict_impl(const Geom& g, const uint16_t* d_frames,
                                hipStream_t s, hipEvent_t* ev) {
   const int with_delta = d_dhigh != nullptr;
   hipError_t e;
-  if ((e = hipMemsetAsync(ws.counters, 0, ws.zero_fixed + (size_t)nframes * kNumHists * 256 * 4, s)) !=
+  if ((e = hipMemsetAsync(ws.counters, 0, ws.zero_fixed, s)) !=
       hipSuccess)
     return e;
   if (ev) hipEventRecord(ev[0], s);
@@ -1891,14 +1924,12 @@ static hipError_t predict_impl(const Geom& g, const uint16_t* d_frames,
 #undef FPV_LAUNCH_STREAM
   }
   if (ev) hipEventRecord(ev[1], s);
-  k_decide_spec<<<nframes, kThreads, 0, s>>>(ws.partials, ws.spec, ws.decision, ws.counters,
-                                            ws.list_a, ws.list_b, g, with_delta);
+  k_decide_spec<<<(nframes + kThreads / 64 - 1) / (kThreads / 64), kThreads, 0, s>>>(
+      ws.partials, ws.spec, ws.decision, ws.counters, ws.list_a, ws.list_b, g, with_delta, nframes);
   if (ev) hipEventRecord(ev[2], s);
-  // exact redo of mis-speculated frames; all three exit at once when the lists are empty
-  k_stats_list<SWAP><<<kListGrid, kThreads, 0, s>>>(d_frames, d_dhigh, ws.counters, ws.list_a,
-                                                   ws.hists, g, with_delta);
-  k_decide_list<<<kListGrid / 4, kThreads, 0, s>>>(ws.hists, ws.decision, ws.counters, ws.list_a,
-                                                  ws.list_b, with_delta);
+  // exact redo of mis-speculated frames; both launches exit at once when the lists are empty
+  k_redo_decide<SWAP><<<kListGrid / 4, kThreads, 0, s>>>(d_frames, d_dhigh, ws.decision, ws.counters,
+                                                        ws.list_a, ws.list_b, g, with_delta);
   k_apply_list<SWAP><<<kListGrid, kThreads, g.lds_bytes, s>>>(
       d_frames, d_dhigh, d_dlow, ws.decision, ws.counters, ws.list_b, d_high, d_low, ws.pv_raw,
       ws.anylow, g);
@@ -1918,8 +1949,9 @@ hipError_t launch_predict(const Geom& g, const uint16_t* d_frames,
                           const uint8_t* d_dlow, const FwdWorkspace& ws,
                           uint8_t* d_high, uint8_t* d_low, uint8_t* d_preview,
                           uint8_t* d_flags, hipStream_t s, hipEvent_t* ev) {
-  static bool attr_set = false;
-  if (!attr_set) {  // tiles above 64 KiB of LDS need the opt-in
+  static std::mutex attr_m;
+  static uint64_t attr_done = 0;
+  once_per_device(attr_m, attr_done, [] {  // tiles above 64 KiB of LDS need the opt-in
 #define FPV_SF(W, F, D, L) reinterpret_cast<const void*>(&k_stream<W, F, D, L>)
     const void* sf[16] = {
         FPV_SF(true, true, true, true),    FPV_SF(true, true, true, false),
@@ -1937,8 +1969,7 @@ hipError_t launch_predict(const Geom& g, const uint16_t* d_frames,
                           reinterpret_cast<const void*>(&k_apply_list<false>)};
     for (const void* f : fns)
       hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-    attr_set = true;
-  }
+  });
   if (g.swap)
     return predict_impl<true>(g, d_frames, nframes, d_dhigh, d_dlow, ws, d_high,
                               d_low, d_preview, d_flags, s, ev);
@@ -1951,16 +1982,16 @@ hipError_t launch_inverse(const Geom& g, const uint8_t* d_high,
                           const uint8_t* d_dlow, const uint8_t* d_flags,
                           uint32_t nframes, uint16_t* d_frames, hipStream_t s,
                           uint32_t* d_diag) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::mutex attr_m;
+  static uint64_t attr_done = 0;
+  once_per_device(attr_m, attr_done, [] {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inverse<true>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inverse<false>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inverse_fast),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-    attr_set = true;
-  }
+  });
   // FPV_INVERSE = spec (default) | fast | slow selects the kernel (tests, A/B timing)
   static const int mode = [] {
     if (getenv("FPV_INVERSE_SLOW")) return 2;

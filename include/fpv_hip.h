@@ -190,6 +190,10 @@ double fpvhip_time_predict_device(fpvhip_ctx *ctx, const void *d_frames,
 /* Diagnostics: the first n (<= 64) dwords of the device-entry-point workspace's
  * counter block after the last predict_device (list sizes, votes, task counter). */
 int fpvhip_debug_counters(fpvhip_ctx *ctx, uint32_t *out, uint32_t n);
+/* Stage timing: milliseconds the slot's stream spent on its last completed batch
+ * (first transfer in -> last transfer out, HIP events on that stream); < 0 when
+ * nothing has completed or a batch is still in flight.  Call after *_wait. */
+double fpvhip_slot_elapsed_ms(fpvhip_ctx *ctx, uint32_t slot);
 /* Diagnostics of the speculative inverse kernel (cc:326-333 replacement), four
  * dwords: out[0] = supersteps, out[1] = chain passes executed by all inverse
  * launches of this context since the last reset (passes / supersteps = average

@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""Time-bounded randomized parity run on the GPU (through the C ABI) against the
+CPU oracle: random geometries, shifts, endianness and content classes through
+predict and inverse, plus inverse on arbitrary planes with forced flags.
+
+  python tools/fuzz_gpu.py [seconds] [seed]      -> one summary line, exit 1 on a mismatch
+"""
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package  # noqa: E402
+from oracle.oracle import Oracle          # noqa: E402  (checker only)
+
+pkg = load_package()
+orc = Oracle()
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+
+
+def content(kind, n, ys, xs):
+    if kind == 0:
+        return rng.integers(0, 65536, (n, ys, xs)).astype(np.uint16)
+    if kind == 1:   # smooth ramps + noise
+        yy, xx = np.mgrid[0:ys, 0:xs]
+        a, b = rng.integers(1, 90, 2)
+        return ((yy * a + xx * b)[None] + rng.integers(0, int(rng.integers(2, 400)), (n, ys, xs))
+                + 3000 * np.arange(n)[:, None, None]).astype(np.uint16)
+    if kind == 2:   # constant rows (identity chains), a step in the middle
+        rows = rng.integers(0, 65536, (n, ys, 1))
+        f = np.repeat(rows, xs, axis=2)
+        f[:, :, xs // 2:] += rng.integers(0, 5000)
+        return f.astype(np.uint16)
+    if kind == 3:   # sparse events on a flat background
+        f = np.full((n, ys, xs), int(rng.integers(0, 65536)), np.int64)
+        m = rng.integers(0, 50, (n, ys, xs)) == 0
+        f[m] = rng.integers(0, 65536, int(m.sum()))
+        return f.astype(np.uint16)
+    if kind == 4:   # zero low bytes / 8-bit data
+        f = rng.integers(0, 65536, (n, ys, xs)).astype(np.uint16)
+        return (f & 0xFF00) if rng.integers(0, 2) else (f >> 8)
+    # blocks of flat values
+    by, bx = int(rng.integers(1, 9)), int(rng.integers(1, 40))
+    small = rng.integers(0, 65536, (n, (ys + by - 1) // by, (xs + bx - 1) // bx))
+    return np.kron(small, np.ones((by, bx), np.int64))[:, :ys, :xs].astype(np.uint16)
+
+
+cases = frames_total = 0
+seen_flags = set()
+t0 = time.time()
+while time.time() - t0 < budget:
+    xs = int(rng.choice([rng.integers(1, 40) * 4, rng.integers(64, 520) * 4, 256, 1280, 1536]))
+    ys = int(rng.integers(1, 24)) * 4
+    be = bool(rng.integers(0, 2))
+    shift = int(rng.choice([0, 0, 4, 8, 2, 6])) if be else int(rng.choice([0, 0, 4, 8, 2, 6, 12]))
+    n = int(rng.integers(1, 6))
+    fr = content(int(rng.integers(0, 6)), n, ys, xs)
+    if rng.integers(0, 4) == 0:
+        fr[1:] = fr[0]          # frames equal to the delta frame
+    delta = fr[0] if rng.integers(0, 5) else None
+    p = pkg.Predictor(xs, ys, shift, be, max_batch=n)
+    if delta is not None:
+        p.set_delta_raw(delta)
+    d = torch.from_numpy(fr.reshape(n, -1).view(np.int16)).cuda().view(torch.uint16)
+    high, low, pv, flags = p.predict(d, with_delta=delta is not None)
+    torch.cuda.synchronize()
+    H, L, P, F = (t.cpu().numpy() for t in (high, low, pv, flags))
+    tag = f"case {cases}: {xs}x{ys} shift={shift} be={be} n={n} delta={delta is not None}"
+    delta16 = None
+    if delta is not None:
+        dh, dl, _ = orc.split(delta, shift, be)
+        delta16 = (dh.astype(np.uint16) << 8) | dl
+        p.set_delta_decoded(delta16)
+    for k in range(n):
+        eh, el, ep, ef = orc.predict(fr[k], xs, ys, shift, be, delta)
+        ok = F[k] == ef and np.array_equal(H[k], eh) and np.array_equal(P[k], ep) and (shift == 8 or np.array_equal(L[k], el))
+        if not ok:
+            print("PREDICT MISMATCH", tag, "frame", k, flush=True)
+            sys.exit(1)
+        seen_flags.add(int(ef))
+    rec = p.inverse(high, low, flags)
+    # inverse on arbitrary planes with every flag combination that is legal here
+    rh = torch.from_numpy(rng.integers(0, 256, H.shape, dtype=np.uint8)).cuda()
+    ff = rng.integers(0, 8, n).astype(np.uint8)
+    if delta is None:
+        ff &= 6
+    rec2 = p.inverse(rh, low, torch.from_numpy(ff).cuda())
+    torch.cuda.synchronize()
+    rec = rec.cpu().view(torch.int16).numpy().view(np.uint16)
+    rec2 = rec2.cpu().view(torch.int16).numpy().view(np.uint16)
+    rhn = rh.cpu().numpy()
+    for k in range(n):
+        e1 = orc.inverse(H[k], None if F[k] & 4 else L[k], delta16, xs, ys, int(F[k]))
+        e2 = orc.inverse(rhn[k], None if ff[k] & 4 else L[k], delta16, xs, ys, int(ff[k]))
+        if not (np.array_equal(rec[k].reshape(-1), np.asarray(e1).reshape(-1))
+                and np.array_equal(rec2[k].reshape(-1), np.asarray(e2).reshape(-1))):
+            print("INVERSE MISMATCH", tag, "frame", k, "flags", F[k], ff[k], flush=True)
+            sys.exit(1)
+    p.close()
+    cases += 1
+    frames_total += n
+print(f"fuzz ok: {cases} cases, {frames_total} frames, flags seen {sorted(seen_flags)}, seed {seed}, {time.time() - t0:.0f} s", flush=True)

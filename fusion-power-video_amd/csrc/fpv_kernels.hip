@@ -1663,6 +1663,302 @@ __global__ __launch_bounds__(64) void k_inverse_spec(
   }
 }
 
+
+// k_inverse_trio: the speculative segmented inverse (see k_inverse_spec) with the
+// work of a frame split over THREE waves of one workgroup, by role:
+//
+//   wave 0 (chain)  north bytes + residuals from LDS -> operands -> passes ->
+//                   reconstructed bytes into the LDS ring.  Issues no global
+//                   memory instruction inside the superstep loop: its instruction
+//                   stream is the frame's critical path and nothing else.
+//   wave 1, wave 2  (i/o, even / odd supersteps) move every byte the frame needs
+//                   from HBM straight into LDS (global_load_lds: no registers, so
+//                   nothing of a load has to be touched before it is used), two to
+//                   three supersteps ahead: residuals for the chain wave, low plane
+//                   and delta planes for themselves; and they run the output phase of
+//                   the superstep the chain wave finished in the previous iteration:
+//                   ring + staged planes -> delta^-1 + recombine -> coalesced stores.
+//
+// One workgroup barrier per superstep hands ring(t) to the i/o waves and the
+// residuals of t+1 to the chain wave.  The barrier is a bare s_barrier behind an
+// LDS-only wait, so the i/o waves' loads stay in flight across it; an i/o wave
+// waits for its own loads (vmcnt) only when it is active again, two iterations
+// after issuing them.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// 64 lanes x 4 bytes from per-lane global addresses into LDS at dst + 4 * lane.
+__device__ __forceinline__ void dma4(const uint8_t* src, uint8_t* dst_wave_uniform) {
+  __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t*>(src),
+                                   reinterpret_cast<uint32_t*>(dst_wave_uniform), 4, 0, 0);
+}
+
+template <int K4>
+__global__ __launch_bounds__(192) void k_inverse_trio(
+    const uint8_t* __restrict__ high, const uint8_t* __restrict__ low,
+    const uint8_t* __restrict__ dhigh, const uint8_t* __restrict__ dlow,
+    const uint8_t* __restrict__ flags, uint16_t* __restrict__ frames, Geom g,
+    uint32_t* __restrict__ pass_count) {
+  constexpr int K = 4 * K4;
+  constexpr uint32_t S = 64u * K;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint8_t* ring = smem;                 // reconstructed high bytes, flat index & m
+  uint8_t* rbuf = smem + g.spec_ring;   // residual bytes of superstep t at rbuf + (t & 3) * S
+  uint8_t* lbuf = rbuf + 4 * S;         // low / delta-high / delta-low bytes of superstep t at lbuf + ((t & 1) * 3 + plane) * S
+  const uint32_t role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t frame = blockIdx.x, lane = threadIdx.x & 63;
+  const size_t fbase = (size_t)frame * g.npix;
+  const uint8_t* hp = high + fbase;
+  const uint8_t* lp = low ? low + fbase : nullptr;
+  uint16_t* outp = frames + fbase;
+  const uint32_t f = flags[frame];
+  const bool use_delta = (f & 1) && dhigh, use_cg = f & 2, no_low = (f & 4) || !lp;
+  const uint32_t xs = g.xs, npix = g.npix, m = g.spec_ring - 1;
+
+  // delta^-1 + recombine (cc:335-344) of 4 pixels; planes that do not exist come as zeros
+  auto emit4 = [&](uint32_t i, uint32_t h4, uint32_t l4, uint32_t dh4, uint32_t dl4) {
+    const uint32_t hh = add4(h4, dh4), ll = add4(l4, dl4);
+    uint2 o;
+    o.x = __builtin_amdgcn_perm(hh, ll, 0x05010400u);
+    o.y = __builtin_amdgcn_perm(hh, ll, 0x07030602u);
+    *reinterpret_cast<uint2*>(outp + i) = o;
+  };
+  const uint8_t* lsrc = no_low ? hp : lp;  // readable dummies for planes that do not exist
+  const uint8_t* dhsrc = use_delta ? dhigh : hp;
+  const uint8_t* dlsrc = use_delta ? dlow : hp;
+  const uint32_t lmask = no_low ? 0u : ~0u, dmask = use_delta ? ~0u : 0u;
+  const uint32_t last4 = npix - 4;  // npix % 4 == 0, npix >= 4
+
+  if (!use_cg) {  // no chain: the three waves stream the frame, 4096 pixels per wave and turn
+    constexpr int U = 4;
+    uint32_t base = role * (U * 1024);
+    for (; base + U * 1024 <= npix; base += 3 * U * 1024) {
+      uint4 h[U], l[U], dh[U], dl[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) h[u] = *reinterpret_cast<const uint4*>(hp + base + u * 1024 + lane * 16);
+      if (!no_low) {
+#pragma unroll
+        for (int u = 0; u < U; u++) l[u] = *reinterpret_cast<const uint4*>(lp + base + u * 1024 + lane * 16);
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; u++) l[u] = make_uint4(0, 0, 0, 0);
+      }
+      if (use_delta) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          dh[u] = *reinterpret_cast<const uint4*>(dhigh + base + u * 1024 + lane * 16);
+          dl[u] = *reinterpret_cast<const uint4*>(dlow + base + u * 1024 + lane * 16);
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; u++) dh[u] = dl[u] = make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const uint32_t hh[4] = {add4(h[u].x, dh[u].x), add4(h[u].y, dh[u].y), add4(h[u].z, dh[u].z), add4(h[u].w, dh[u].w)};
+        const uint32_t ll[4] = {add4(l[u].x, dl[u].x), add4(l[u].y, dl[u].y), add4(l[u].z, dl[u].z), add4(l[u].w, dl[u].w)};
+        uint4 a, b2;
+        a.x = __builtin_amdgcn_perm(hh[0], ll[0], 0x05010400u); a.y = __builtin_amdgcn_perm(hh[0], ll[0], 0x07030602u);
+        a.z = __builtin_amdgcn_perm(hh[1], ll[1], 0x05010400u); a.w = __builtin_amdgcn_perm(hh[1], ll[1], 0x07030602u);
+        b2.x = __builtin_amdgcn_perm(hh[2], ll[2], 0x05010400u); b2.y = __builtin_amdgcn_perm(hh[2], ll[2], 0x07030602u);
+        b2.z = __builtin_amdgcn_perm(hh[3], ll[3], 0x05010400u); b2.w = __builtin_amdgcn_perm(hh[3], ll[3], 0x07030602u);
+        uint16_t* op = outp + base + u * 1024 + lane * 16;
+        *reinterpret_cast<uint4*>(op) = a;
+        *reinterpret_cast<uint4*>(op + 8) = b2;
+      }
+    }
+    // tail (fewer than 3 x 4096 pixels): the first pixel no wave has covered, split by thread
+    const uint32_t done = (npix / (U * 1024)) * (U * 1024);
+    for (uint32_t i = done + threadIdx.x * 4; i < npix; i += 192 * 4)
+      emit4(i, *reinterpret_cast<const uint32_t*>(hp + i),
+            *reinterpret_cast<const uint32_t*>(lsrc + i) & lmask,
+            *reinterpret_cast<const uint32_t*>(dhsrc + i) & dmask,
+            *reinterpret_cast<const uint32_t*>(dlsrc + i) & dmask);
+    return;
+  }
+
+  const uint32_t head = min(xs + 4, npix);
+  const uint32_t nsteps = (npix - head + S - 1) / S;
+  uint32_t w_prev = 0, npass = 0, maxpass = 0;  // chain wave
+
+  // i/o waves: stage superstep t's residuals / planes into LDS (coalesced layout:
+  // dword k * 64 + lane).  Indices are clamped into the frame; what lies beyond the
+  // last pixel is never emitted and never anybody's north.
+  auto dma_r = [&](uint32_t t) {
+#pragma unroll
+    for (int k = 0; k < K4; k++)
+      dma4(hp + min(head + t * S + (k * 64 + lane) * 4, last4), rbuf + (t & 3) * S + k * 256);
+  };
+  auto dma_ldh = [&](uint32_t t) {
+    uint8_t* base = lbuf + (t & 1) * 3 * S;
+#pragma unroll
+    for (int k = 0; k < K4; k++) {
+      const uint32_t ic = min(head + t * S + (k * 64 + lane) * 4, last4);
+      dma4(lsrc + ic, base + k * 256);
+      dma4(dhsrc + ic, base + S + k * 256);
+      dma4(dlsrc + ic, base + 2 * S + k * 256);
+    }
+  };
+
+  if (role == 0) {
+    // Head: the first xs + 1 pixels are literals (cc:327 starts at xs + 1); pixels
+    // xs+1 .. xs+3 are walked serially so that the supersteps start 4-aligned.
+    for (uint32_t o = lane * 4; o < head; o += 256)
+      *reinterpret_cast<uint32_t*>(ring + (o & m)) = *reinterpret_cast<const uint32_t*>(hp + o);
+    wave_lds_sync();
+    {
+      int w = ring[xs & m];
+      for (uint32_t i = xs + 1; i < head; i++) {
+        const int x = (ring[i & m] + cg_pred(ring[(i - xs) & m], w, ring[(i - xs - 1) & m])) & 0xff;
+        ring[i & m] = (uint8_t)x;  // every lane writes the same value
+        w = x;
+      }
+    }
+    wave_lds_sync();
+    for (uint32_t o = lane * 4; o < head; o += 256)
+      emit4(o, *reinterpret_cast<const uint32_t*>(ring + (o & m)),
+            *reinterpret_cast<const uint32_t*>(lsrc + o) & lmask,
+            *reinterpret_cast<const uint32_t*>(dhsrc + o) & dmask,
+            *reinterpret_cast<const uint32_t*>(dlsrc + o) & dmask);
+    w_prev = (uint32_t)ring[(head - 1) & m] << 8;  // wave-uniform: final x[s-1] << 8
+  } else if (role == 1) {  // even supersteps: residuals of 0 and 2, planes of 0
+    dma_r(0);
+    dma_r(2);
+    dma_ldh(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {  // odd supersteps: residuals of 1 (3 and the planes of 1 follow in iteration 0)
+    dma_r(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  lds_barrier();
+
+  for (uint32_t t = 0; t <= nsteps; t++) {
+    if (role == 0) {
+      if (t < nsteps) {
+        const uint32_t s0 = head + t * S, start = s0 + lane * K;
+        const bool active = start < npix;
+        uint32_t N[K], D[K], R[K], X[K];
+        uint32_t guess;
+        {
+          const uint32_t nb = start - xs - 4;  // dword holding the north-west of the first pixel
+          uint32_t nd[K4 + 1], rq[K4];
+#pragma unroll
+          for (int q = 0; q <= K4; q++) nd[q] = *reinterpret_cast<const uint32_t*>(ring + ((nb + 4 * q) & m));
+#pragma unroll
+          for (int q = 0; q < K4; q++) rq[q] = *reinterpret_cast<const uint32_t*>(rbuf + (t & 3) * S + lane * K + 4 * q);
+          uint32_t prev = __builtin_amdgcn_perm(0, nd[0], 0x0c0c030cu);
+          guess = prev;  // x[start - 1 - xs] << 8
+#pragma unroll
+          for (int q = 0; q < K4; q++) {
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+              const uint32_t sel = 0x0c0c000cu | ((uint32_t)b << 8);
+              const uint32_t n = __builtin_amdgcn_perm(0, nd[q + 1], sel);
+              N[4 * q + b] = n;
+              D[4 * q + b] = n - prev;
+              R[4 * q + b] = __builtin_amdgcn_perm(0, rq[q], sel);
+              prev = n;
+            }
+          }
+        }
+        uint32_t in = lane == 0 ? w_prev : guess;
+        bool run = true;
+        const uint32_t npass0 = npass;
+        bool settled = false;
+        for (uint32_t round = 0; round < kScanAfter; round++) {  // the common case ends in here
+          if (run) {
+            uint32_t w = in;
+#pragma unroll
+            for (int k = 0; k < K; k++) X[k] = w = inv_px(N[k], w, D[k], R[k]);
+          }
+          npass++;
+          uint32_t pred = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)X[K - 1], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+          if (lane == 0) pred = w_prev;
+          run = active && pred != in;
+          if (!__builtin_amdgcn_ballot_w64(run)) { settled = true; break; }
+          in = pred;
+        }
+        if (__builtin_expect(!settled, 0)) {  // long correction chain: see k_inverse_spec
+          uint32_t all, ord = 0, sum = 0;
+          asm volatile("v_mov_b32 %0, -1" : "=v"(all));
+#pragma unroll
+          for (int k = 0; k < K; k++) { ord = max(ord, D[k] & all); sum += R[k] & all; }
+          const bool is_shift = ord == 0 && lane != 0;
+          const uint32_t ssum = sum & 0xffffu;
+          for (;;) {
+            if (run) {
+              uint32_t w = in;
+#pragma unroll
+              for (int k = 0; k < K; k++) X[k] = w = inv_px(N[k], w, D[k], R[k]);
+            }
+            npass++;
+            uint32_t pred = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)X[K - 1], 0x138, 0xf, 0xf, false);
+            if (lane == 0) pred = w_prev;
+            const bool bad = active && pred != in;
+            if (!__builtin_amdgcn_ballot_w64(bad)) break;
+            uint32_t next_in = pred;
+            if (npass - npass0 < kScanUntil) {
+              uint32_t isc = is_shift ? 0u : 1u, v = is_shift ? ssum : X[K - 1];
+#pragma unroll
+              for (int dlt = 1; dlt < 64; dlt <<= 1) {
+                const uint32_t isc_l = __shfl_up(isc, dlt, 64), v_l = __shfl_up(v, dlt, 64);
+                if (lane >= (uint32_t)dlt && !isc) {
+                  v = (v + v_l) & 0xffffu;
+                  isc = isc_l;
+                }
+              }
+              next_in = __shfl_up(v, 1, 64);
+              if (lane == 0) next_in = w_prev;
+            }
+            run = active && next_in != in;
+            in = next_in;
+          }
+        }
+        maxpass = max(maxpass, npass - npass0);
+        w_prev = (uint32_t)__builtin_amdgcn_readlane((int)X[K - 1], 63);
+#pragma unroll
+        for (int q = 0; q < K4; q++) {
+          const uint32_t o = __builtin_amdgcn_perm(X[4 * q + 1], X[4 * q], 0x0c0c0501u) |
+                             __builtin_amdgcn_perm(X[4 * q + 3], X[4 * q + 2], 0x05010c0cu);
+          *reinterpret_cast<uint32_t*>(ring + ((start + 4 * q) & m)) = o;
+        }
+      }
+    } else if (((t + 1) & 1u) == role - 1) {  // i/o wave of the parity of superstep t - 1 (and t + 1, t + 3)
+      // everything this wave issued two iterations ago has landed: planes of t - 1, residuals of t + 1
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (t >= 1) {  // output phase of superstep t - 1
+        const uint32_t s0 = head + (t - 1) * S;
+        const uint8_t* base = lbuf + ((t - 1) & 1) * 3 * S;
+        uint32_t h4[K4], l4[K4], dh4[K4], dl4[K4];
+#pragma unroll
+        for (int k = 0; k < K4; k++) {
+          const uint32_t o = (k * 64 + lane) * 4;
+          h4[k] = *reinterpret_cast<const uint32_t*>(ring + ((s0 + o) & m));
+          l4[k] = *reinterpret_cast<const uint32_t*>(base + o) & lmask;
+          dh4[k] = *reinterpret_cast<const uint32_t*>(base + S + o) & dmask;
+          dl4[k] = *reinterpret_cast<const uint32_t*>(base + 2 * S + o) & dmask;
+        }
+#pragma unroll
+        for (int k = 0; k < K4; k++) {
+          const uint32_t i = s0 + (k * 64 + lane) * 4;
+          if (i < npix) emit4(i, h4[k], l4[k], dh4[k], dl4[k]);
+        }
+        wave_lds_sync();  // the reads above are done before the next planes overwrite the buffer
+      }
+      if (t + 1 < nsteps) dma_ldh(t + 1);
+      if (t + 3 < nsteps) dma_r(t + 3);
+    }
+    lds_barrier();
+  }
+  if (pass_count && role == 0 && lane == 0) {  // diagnostics: supersteps and passes (bench / tests)
+    atomicAdd(&pass_count[0], nsteps);
+    atomicAdd(&pass_count[1], npass);
+    atomicMax(&pass_count[2], npass);
+    atomicMax(&pass_count[3], maxpass);
+  }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------- host side ---
@@ -1992,15 +2288,42 @@ hipError_t launch_inverse(const Geom& g, const uint8_t* d_high,
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inverse_fast),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
   });
-  // FPV_INVERSE = spec (default) | fast | slow selects the kernel (tests, A/B timing)
-  static const int mode = [] {
-    if (getenv("FPV_INVERSE_SLOW")) return 2;
-    const char* e = getenv("FPV_INVERSE");
-    if (!e) return 0;
-    return e[0] == 'f' ? 1 : e[0] == 's' && e[1] == 'l' ? 2 : 0;
-  }();
+  // FPV_INVERSE = auto (default) | trio | spec | fast | slow selects the kernel (tests, A/B timing).
+  // auto: three waves per frame (shorter serial path per frame) while every frame's
+  // chain wave can have a SIMD to itself most of the time, one wave per frame (less
+  // synchronisation, more frames resident) for larger batches.  Measured crossover
+  // on MI355X (256 CUs): between 768 and 1000 frames.
+  int mode = -1;  // read per launch: tests switch kernels inside one process
+  if (getenv("FPV_INVERSE_SLOW")) {
+    mode = 2;
+  } else if (const char* e = getenv("FPV_INVERSE")) {
+    mode = e[0] == 'f' ? 1 : e[0] == 's' && e[1] == 'l' ? 2 : e[0] == 's' ? 0 : e[0] == 't' ? 3 : -1;
+  }
+  if (mode < 0) {
+    static int ncu = 0;
+    if (!ncu) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+        ncu = prop.multiProcessorCount;
+      if (ncu <= 0) ncu = 256;
+    }
+    mode = nframes <= 3u * (uint32_t)ncu ? 3 : 0;
+  }
   const bool aligned = (g.xs & 3) == 0 && (g.npix & 3) == 0;
-  if (mode == 0 && g.spec_k4) {
+  if (mode == 3 && g.spec_k4) {
+#define FPV_LAUNCH_TRIO(K4)                                                                     \
+  case K4:                                                                                      \
+    k_inverse_trio<K4><<<nframes, 192, g.spec_ring + 10 * 256 * K4, s>>>(                       \
+        d_high, d_low, d_dhigh, d_dlow, d_flags, d_frames, g, d_diag);                          \
+    break;
+    switch (g.spec_k4) {
+      FPV_LAUNCH_TRIO(1) FPV_LAUNCH_TRIO(2) FPV_LAUNCH_TRIO(3)
+      FPV_LAUNCH_TRIO(4) FPV_LAUNCH_TRIO(5) FPV_LAUNCH_TRIO(6)
+      default: return hipErrorInvalidValue;
+    }
+#undef FPV_LAUNCH_TRIO
+  } else if (mode == 0 && g.spec_k4) {
 #define FPV_LAUNCH_SPEC(K4)                                                                  \
   case K4:                                                                                   \
     k_inverse_spec<K4><<<nframes, 64, g.spec_ring, s>>>(d_high, d_low, d_dhigh, d_dlow,      \

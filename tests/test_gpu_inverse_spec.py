@@ -13,6 +13,20 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["spec", "trio"])
+def inverse_kernel(request):
+    """Every test of this file runs once per speculative kernel: the one-wave-per-frame
+    form (large batches) and the three-wave form (small batches); by default the
+    library picks by batch size, which would leave one of them untested here."""
+    old = os.environ.get("FPV_INVERSE")
+    os.environ["FPV_INVERSE"] = request.param
+    yield request.param
+    if old is None:
+        os.environ.pop("FPV_INVERSE", None)
+    else:
+        os.environ["FPV_INVERSE"] = old
+
+
 def _inverse_case(fpv, oracle, high, low, flags, xs, ys, delta16=None):
     import torch
     n = high.shape[0]

@@ -88,11 +88,12 @@ def test_partial_batches_reuse_workspace(fpv, synth, oracle):
 
 
 @pytest.mark.parametrize("env", [{"FPV_STRIP_ROWS": "4"}, {"FPV_STRIP_ROWS": "80", "FPV_STRIP_MAJOR": "0"}, {"FPV_STRIP_ROWS": "12", "FPV_WAVES_PER_CU": "2"},
-                                 {"FPV_INVERSE_SLOW": "1"}])
+                                 {"FPV_INVERSE_SLOW": "1"}, {"FPV_INVERSE": "fast"}, {"FPV_INVERSE": "spec"},
+                                 {"FPV_INVERSE": "trio"}])
 def test_alternate_kernel_paths(fpv, synth, oracle, env):
     """Odd strip sizes (partial last steps, non-FAST streaming variant), the
-    frame-major task order and the generic inverse kernel must give the same
-    bits as the default paths."""
+    frame-major task order and every inverse kernel (byte-granular, serial chain,
+    one-wave and three-wave speculative) must give the same bits as the defaults."""
     import os
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)

@@ -8,7 +8,7 @@ from oracle.oracle import Oracle
 orc = Oracle()
 XS, YS = 1280, 800
 ns = [int(a) for a in sys.argv[1:]] or [1, 64, 1024, 4096]
-print("FPV_INVERSE =", os.environ.get("FPV_INVERSE", "spec (default)"))
+print("FPV_INVERSE =", os.environ.get("FPV_INVERSE", "trio (default)"))
 for n in ns:
     base = synth.plasma_frames(min(n, 8) + 1, XS, YS, bits=12)
     pred = pkg.Predictor(XS, YS, 4, False, max_batch=n); pred.set_delta_raw(base[0])

@@ -65,6 +65,7 @@ while time.time() - t0 < budget:
     if rng.integers(0, 4) == 0:
         fr[1:] = fr[0]          # frames equal to the delta frame
     delta = fr[0] if rng.integers(0, 5) else None
+    os.environ["FPV_INVERSE"] = str(rng.choice(["spec", "trio", "auto", "fast"], p=[0.4, 0.4, 0.1, 0.1]))  # read per launch
     p = pkg.Predictor(xs, ys, shift, be, max_batch=n)
     if delta is not None:
         p.set_delta_raw(delta)

@@ -718,10 +718,17 @@ __global__ __launch_bounds__(64, 4) void k_stream(
   const uint32_t row_l = (c.lane * 16) / g.xs, col_l = (c.lane * 16) % g.xs;
 
   const uint32_t ntasks = g.nframes * g.strips;
+  // The first task of a wave is its workgroup index; only later ones come from the
+  // device-wide counter (2048 waves hitting one word at launch would queue for ~25 us:
+  // same-address atomics serialise at ~12 ns).
+  bool first = true;
   for (;;) {
-    uint32_t task = 0;
-    if (c.lane == 0) task = atomicAdd(&counters[6], 1u);
-    task = __builtin_amdgcn_readfirstlane(task);
+    uint32_t task = blockIdx.x;
+    if (!first) {
+      if (c.lane == 0) task = gridDim.x + atomicAdd(&counters[6], 1u);
+      task = __builtin_amdgcn_readfirstlane(task);
+    }
+    first = false;
     if (task >= ntasks) {
 #ifdef FPV_STAMPS
       if (c.lane == 0)  // stamps leave through a buffer nothing else reads (counters[16..27])

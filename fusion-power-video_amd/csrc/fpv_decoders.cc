@@ -374,7 +374,14 @@ void StreamingDecoder::Decode(
 // ===================================================== RandomAccessDecoder ==
 
 struct RandomAccessDecoder::State {
-  std::shared_ptr<InverseEngine> engine;   // full frames
+  std::shared_ptr<InverseEngine> engine;   // full frames (first device)
+  // DecodeFrames shards large requests over every visible GPU (FPV_DEVICES): frames
+  // depend only on the delta frame, so the shards never exchange anything.  Engines of
+  // the other devices are created on first need.
+  std::vector<int> devices;
+  std::vector<std::shared_ptr<InverseEngine>> more;   // devices[1..]
+  std::vector<uint16_t> delta16;
+  uint32_t batch = 1;
   std::shared_ptr<InverseEngine> preview;  // (xs/4) x (ys/4), created on first use
   std::mutex m;
 };
@@ -398,13 +405,16 @@ bool RandomAccessDecoder::Init(const uint8_t* data, size_t size) {
 
   state_ = std::make_shared<State>();
   const uint32_t batch = DecodeBatchFrames(xsize_ * ysize_);
-  state_->engine = InverseEngine::Create(xsize_, ysize_, batch, 2, DecoderDevice());
+  state_->devices = DeviceList();
+  state_->batch = batch;
+  state_->engine = InverseEngine::Create(xsize_, ysize_, batch, 2, state_->devices[0]);
   if (!state_->engine) return FPV_FAILURE("no GPU decoder");
   const uint16_t* px = nullptr;
   int slot = -1;
   if (!state_->engine->Decode(data + pos + 5, dsz - 5, &px, &slot))
     return FPV_FAILURE("failed to decode delta frame");
   const bool set = state_->engine->SetDelta(px);
+  if (set) state_->delta16.assign(px, px + xsize_ * ysize_);
   state_->engine->Release(slot);
   if (!set) return FPV_FAILURE("failed to decode delta frame");
 
@@ -463,9 +473,38 @@ bool RandomAccessDecoder::DecodeFrames(const size_t* indices, size_t count,
   for (size_t i = 0; i < count; i++)
     if (!FindMain(data_, size_, frame_offsets_, indices[i], &ins[i], &sizes[i])) return false;
   const size_t bytes = xsize_ * ysize_ * 2;
-  return state_->engine->DecodeBatch(
-      ins.data(), sizes.data(), count,
-      [&](size_t i, const uint16_t* px) { memcpy(out[i], px, bytes); }, threads);
+  State& st = *state_;
+  // One shard per GPU when every shard still fills a batch; otherwise the first GPU alone.
+  size_t shards = std::min(st.devices.size(), count / std::max<size_t>(1, st.batch));
+  if (shards < 2) {
+    return st.engine->DecodeBatch(
+        ins.data(), sizes.data(), count,
+        [&](size_t i, const uint16_t* px) { memcpy(out[i], px, bytes); }, threads);
+  }
+  {
+    std::lock_guard<std::mutex> l(st.m);
+    while (st.more.size() + 1 < shards) {
+      auto e = InverseEngine::Create(xsize_, ysize_, st.batch, 2, st.devices[st.more.size() + 1]);
+      if (!e || !e->SetDelta(st.delta16.data())) return FPV_FAILURE("no GPU decoder on a further device");
+      st.more.push_back(e);
+    }
+  }
+  std::vector<char> ok(shards, 0);
+  std::vector<std::thread> pool;
+  const size_t per = (count + shards - 1) / shards, th = std::max<size_t>(1, threads / shards);
+  for (size_t g = 0; g < shards; g++) {
+    pool.emplace_back([&, g] {
+      const size_t first = g * per, n = first < count ? std::min(per, count - first) : 0;
+      InverseEngine* e = g == 0 ? st.engine.get() : st.more[g - 1].get();
+      ok[g] = n == 0 || e->DecodeBatch(
+                            ins.data() + first, sizes.data() + first, n,
+                            [&, first](size_t i, const uint16_t* px) { memcpy(out[first + i], px, bytes); }, th);
+    });
+  }
+  for (auto& t : pool) t.join();
+  for (size_t g = 0; g < shards; g++)
+    if (!ok[g]) return false;
+  return true;
 }
 
 // cc:1038-1070

@@ -155,8 +155,9 @@ def test_unextract_matches_oracle(codec, oracle, synth):
 
 
 def test_in_process_multi_device_round_robin(tmp_path, synth):
-    """Encoder shards batches over every visible device (batch b -> device b mod G).
-    The CPU shim can pose as several devices: the stream must not change."""
+    """Encoder shards batches over every visible device (batch b -> device b mod G)
+    and RandomAccessDecoder::DecodeFrames shards its frame list the same way.
+    The CPU shim can pose as several devices: stream and pixels must not change."""
     import subprocess
     import sys
     if not os.path.exists(SHIM):
@@ -168,18 +169,25 @@ from conftest import load_package
 load_package()
 synth = importlib.import_module("fpv_amd.synth"); codec = importlib.import_module("fpv_amd.codec").Codec(sys.argv[2])
 fr = synth.noise_frames(70, 64, 48, seed=9)
-print("SHA", hashlib.sha256(codec.encode_stream(fr, fr[0], 64, 48, threads=4).tobytes()).hexdigest())
+fpv = codec.encode_stream(fr, fr[0], 64, 48, threads=4)
+print("SHA", hashlib.sha256(fpv.tobytes()).hexdigest())
+# batched random-access decode: 70 frames, batches of 16 -> one shard per visible device
+import numpy as np
+dec = codec.decode_stream(fpv, batched=True, threads=4)
+assert np.array_equal(dec, fr), "sharded DecodeFrames differs"
+print("DECODE ok")
 '''
     script = tmp_path / "multi.py"
     script.write_text(code)
     root = os.path.dirname(HERE)
     shas = []
     for ndev, devs in ((1, None), (3, None), (4, "1,3")):
-        env = dict(os.environ, FPV_SHIM_DEVICES=str(ndev))
+        env = dict(os.environ, FPV_SHIM_DEVICES=str(ndev), FPV_DECODE_BATCH="16")
         if devs:
             env["FPV_DEVICES"] = devs
         out = subprocess.run([sys.executable, str(script), root, SHIM], env=env, capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stdout + out.stderr
+        assert "DECODE ok" in out.stdout, out.stdout + out.stderr
         shas.append([l for l in out.stdout.splitlines() if l.startswith("SHA")][0])
     assert shas[0] == shas[1] == shas[2]
 

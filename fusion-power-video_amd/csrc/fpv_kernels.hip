@@ -4,12 +4,15 @@
 //
 // Reference loops replaced ("cc:N" = fusion_power_video.cc of the upstream
 // CPU library):
-//   k_stats            heuristic histograms                cc:526-531, cc:554-562
-//   k_decide           EstimateEntropy + the two decisions cc:235-244, cc:533, cc:564
-//   k_apply            split + preview sums + delta + CG   cc:391-443, cc:500-512,
-//                                                          cc:534-537, cc:566-572
-//   k_preview_finish   preview CG + flags byte             cc:575-586, cc:447-449
-//   k_inverse          CG^-1, delta^-1, recombine          cc:326-344
+//   k_stream           split + preview sums + delta + CG under speculated flags,
+//                      heuristic histograms in the same pass   cc:391-443, cc:500-512,
+//                                                              cc:526-537, cc:554-572
+//   k_decide_spec      EstimateEntropy + the two decisions     cc:235-244, cc:533, cc:564
+//   k_redo_decide / k_apply_list
+//                      exact redo of mis-speculated frames     (same lines)
+//   k_finish           preview CG + flags byte                 cc:575-586, cc:447-449
+//   k_inverse_spec / k_inverse_trio / k_inverse(_fast)
+//                      CG^-1, delta^-1, recombine              cc:326-344
 //
 // Neighbourhoods are FLAT 1-D (w = i-1, n = i-xs, nw = i-xs-1 on the flattened
 // plane, cc:556-558): column 0's west neighbour is the previous row's last

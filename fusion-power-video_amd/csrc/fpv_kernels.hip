@@ -1,6 +1,7 @@
 // fpv_kernels.hip -- gfx950 (CDNA4) kernels of the fusion-power-video
-// predictor/residual stage.  Pure 8/16-bit integer filtering: no MFMA, the
-// bound is HBM bandwidth (forward) or dependency latency (inverse).
+// predictor/residual stage.  Pure 8/16-bit integer filtering: no MFMA; the
+// bound is HBM bandwidth (forward, and inverse with enough frames in flight) or
+// one wave's issue rate (inverse of few frames).
 //
 // Reference loops replaced ("cc:N" = fusion_power_video.cc of the upstream
 // CPU library):

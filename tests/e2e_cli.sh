@@ -1,6 +1,6 @@
 #!/bin/bash
-# End-to-end check on the GPU box: upstream CLI sources linked against our
-# library vs the CPU reference binaries (oracle/_ref), same input, SHA-256.
+# TEST SCRIPT.  End-to-end check on the GPU box: upstream CLI sources linked against
+# our library vs the CPU reference binaries (oracle/_ref, the checker), same input, SHA-256.
 # Every step runs under its own timeout; big scratch files go to /tmp.
 set -u
 cd "$(dirname "$0")/.."

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Time-bounded randomized parity run on the GPU (through the C ABI) against the
-CPU oracle: random geometries, shifts, endianness and content classes through
+CPU oracle (test infrastructure, like everything under tests/): random geometries, shifts, endianness and content classes through
 predict and inverse, plus inverse on arbitrary planes with forced flags.
 
-  python tools/fuzz_gpu.py [seconds] [seed]      -> one summary line, exit 1 on a mismatch
+  python tests/fuzz_gpu.py [seconds] [seed]      -> one summary line, exit 1 on a mismatch
 """
 import importlib
 import os

@@ -4,8 +4,6 @@ import sys, os, importlib, numpy as np, torch
 sys.path.insert(0, '.')
 from __graft_entry__ import load_package
 pkg = load_package(); synth = importlib.import_module('fpv_amd.synth')
-from oracle.oracle import Oracle
-orc = Oracle()
 XS, YS = 1280, 800
 ns = [int(a) for a in sys.argv[1:]] or [1, 64, 1024, 4096]
 print("FPV_INVERSE =", os.environ.get("FPV_INVERSE", "trio (default)"))
@@ -16,7 +14,7 @@ for n in ns:
     d = torch.from_numpy(src.reshape(src.shape[0], -1).view(np.int16)).cuda()
     fr = d[torch.arange(n, device='cuda') % src.shape[0]].contiguous().view(torch.uint16)
     high, low, pv, flags = pred.predict(fr)
-    dh, dl, _ = orc.split(base[0], 4, False); pred.set_delta_decoded((dh.astype(np.uint16) << 8) | dl)
+    pred.set_delta_decoded((base[0].astype(np.uint16) << 4).astype(np.uint16))  # the decoded delta frame = left-aligned delta image
     out = torch.empty((n, YS, XS), dtype=torch.uint16, device='cuda')
     pred.inverse_pass_stats(reset=True)
     pred.inverse(high, low, flags, out=out); torch.cuda.synchronize()

@@ -3,6 +3,7 @@
 // whole thing can run under ThreadSanitizer (`make tsan`).
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -19,7 +20,13 @@ int main() {
   std::vector<uint16_t> fr(n * xs * ys);
   uint32_t s = 12345;
   for (auto& v : fr) { s = s * 1664525u + 1013904223u; v = (s >> 16) & 0xfff; }
+  const int ndev_of[4] = {1, 1, 3, 2};  // the shim poses as several devices: sharded encode / decode
+  int round = 0;
+  setenv("FPV_DECODE_BATCH", "16", 1);
   for (int threads : {0, 1, 3, 8}) {
+    char nd[8];
+    snprintf(nd, sizeof nd, "%d", ndev_of[round++]);
+    setenv("FPV_SHIM_DEVICES", nd, 1);
     std::vector<uint8_t> out;
     {
       fpvc::Encoder enc(threads, 4, false);
@@ -44,6 +51,11 @@ int main() {
       sd.Decode(out.data() + pos, out.size() - pos < 1000 ? out.size() - pos : 1000,
                 [](bool ok, uint16_t*, size_t, size_t, void* p) { if (ok) ++*static_cast<size_t*>(p); }, &got);
     if (got != n) return 4;
+    got = 0;  // the whole file in one call: GPU batches + threaded Brotli inside Decode
+    fpvc::StreamingDecoder whole;
+    whole.Decode(out.data(), out.size(),
+                 [](bool ok, uint16_t*, size_t, size_t, void* p) { if (ok) ++*static_cast<size_t*>(p); }, &got);
+    if (got != n) return 5;
     printf("threads %d ok, %zu bytes\n", threads, out.size());
   }
   return 0;

@@ -34,6 +34,8 @@ def declare(lib):
     lib.fpvc_decode_stream.restype = c.c_long
     lib.fpvc_decode_stream.argtypes = [_u8p, c.c_size_t, _u16p, c.c_size_t, c.c_void_p, c.c_int,
                                        c.c_size_t]
+    lib.fpvc_decode_stream_raw.restype = c.c_long
+    lib.fpvc_decode_stream_raw.argtypes = [_u8p, c.c_size_t, _u8p, c.c_size_t, c.c_int, c.c_int, c.c_size_t]
     lib.fpvc_stream_decode.restype = c.c_long
     lib.fpvc_stream_decode.argtypes = [_u8p, c.c_size_t, c.c_size_t, _u16p, c.c_size_t]
     lib.fpvc_stream_info.restype = c.c_int
@@ -110,6 +112,16 @@ class Codec:
         if with_previews:
             return frames, pv[:got * (xs // 4) * (ys // 4)].reshape(got, ys // 4, xs // 4)
         return frames
+
+    def decode_stream_raw(self, data, shift=0, big_endian=False, threads=4):
+        """Whole stream -> raw file bytes per frame (UnextractFrame fused on the GPU)."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        xs, ys, n = self.stream_info(data)
+        out = np.zeros(max(n, 1) * xs * ys * 2, np.uint8)
+        got = self.lib.fpvc_decode_stream_raw(data, data.size, out, n, shift, int(big_endian), threads)
+        if got < 0:
+            raise RuntimeError("decode_stream_raw failed")
+        return out[:got * xs * ys * 2].reshape(got, xs * ys * 2)
 
     def stream_decode(self, data, xs, ys, nframes, block=65536):
         data = np.ascontiguousarray(data, dtype=np.uint8)

@@ -84,6 +84,23 @@ long fpvc_decode_stream(const uint8_t* data, size_t size, uint16_t* frames_out,
   return static_cast<long>(n);
 }
 
+long fpvc_decode_stream_raw(const uint8_t* data, size_t size, uint8_t* raw_out, size_t cap_frames,
+                            int shift, int big_endian, size_t threads) {
+  fpvc::RandomAccessDecoder dec;
+  if (!dec.Init(data, size)) return -1;
+  const size_t n = dec.numframes();
+  if (n > cap_frames) return -1;
+  const size_t fbytes = dec.xsize() * dec.ysize() * 2;
+  std::vector<size_t> idx(n);
+  std::vector<uint8_t*> outs(n);
+  for (size_t i = 0; i < n; i++) {
+    idx[i] = i;
+    outs[i] = raw_out + i * fbytes;
+  }
+  if (n && !dec.DecodeFramesRaw(idx.data(), n, outs.data(), shift, big_endian != 0, threads)) return -1;
+  return static_cast<long>(n);
+}
+
 long fpvc_stream_decode(const uint8_t* data, size_t size, size_t block,
                         uint16_t* frames_out, size_t cap_frames) {
   struct St {

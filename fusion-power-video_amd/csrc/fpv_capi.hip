@@ -356,10 +356,17 @@ uint8_t* fpvhip_stage_plane(fpvhip_ctx* c, uint32_t slot, uint32_t k, int which)
 }
 
 static int inverse_submit_impl(fpvhip_ctx* c, uint32_t slot, uint32_t nframes,
-                               const uint8_t* flags, bool to_planes);
+                               const uint8_t* flags, bool to_planes, int unshift = -1,
+                               int big_endian = 0);
 
 int fpvhip_inverse_submit(fpvhip_ctx* c, uint32_t slot, uint32_t nframes, const uint8_t* flags) {
   return inverse_submit_impl(c, slot, nframes, flags, false);
+}
+
+int fpvhip_inverse_submit_raw(fpvhip_ctx* c, uint32_t slot, uint32_t nframes, const uint8_t* flags,
+                              int unshift, int big_endian) {
+  if (unshift < 0 || unshift > 15) return fail(c, "unshift must be 0..15");
+  return inverse_submit_impl(c, slot, nframes, flags, false, unshift, big_endian);
 }
 
 int fpvhip_inverse_planes_submit(fpvhip_ctx* c, uint32_t slot, uint32_t nframes,
@@ -370,7 +377,7 @@ int fpvhip_inverse_planes_submit(fpvhip_ctx* c, uint32_t slot, uint32_t nframes,
 }
 
 static int inverse_submit_impl(fpvhip_ctx* c, uint32_t slot, uint32_t nframes,
-                               const uint8_t* flags, bool to_planes) {
+                               const uint8_t* flags, bool to_planes, int unshift, int big_endian) {
   if (check_slot(c, slot)) return -1;
   if (nframes == 0 || nframes > c->max_batch || !flags) return fail(c, "bad arguments");
   Slot& s = c->slots[slot];
@@ -396,6 +403,8 @@ static int inverse_submit_impl(fpvhip_ctx* c, uint32_t slot, uint32_t nframes,
     HIPOK(c, hipMemcpyAsync(s.h_high, s.d_high, nframes * np, hipMemcpyDeviceToHost, s.stream));
     HIPOK(c, hipMemcpyAsync(s.h_low, s.d_low, nframes * np, hipMemcpyDeviceToHost, s.stream));
   } else {
+    if (unshift >= 0)  // UnextractFrame (cc:850-862) fused in front of the copy back
+      HIPOK(c, fpvhip::launch_unextract(s.d_pix, nframes * np, unshift, big_endian, s.stream));
     HIPOK(c, hipMemcpyAsync(s.h_pix, s.d_pix, nframes * np * 2, hipMemcpyDeviceToHost, s.stream));
   }
   HIPOK(c, hipEventRecord(s.done, s.stream));

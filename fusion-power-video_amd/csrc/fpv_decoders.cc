@@ -174,7 +174,7 @@ bool InverseEngine::Decode(const uint8_t* in, size_t size, const uint16_t** fram
 }
 
 bool InverseEngine::DecodeBatch(const uint8_t* const* ins, const size_t* sizes, size_t n,
-                                const Sink& sink, size_t threads) {
+                                const Sink& sink, size_t threads, int unshift, bool big_endian) {
   if (threads == 0) threads = 1;
   // Two slots alternate: while the GPU inverts batch g, the host threads
   // Brotli-decode batch g+1 into the other slot.
@@ -219,7 +219,10 @@ bool InverseEngine::DecodeBatch(const uint8_t* const* ins, const size_t* sizes, 
     for (auto& t : pool) t.join();
     size_t usable = 0;  // images in front of the first failure
     while (usable < count && good[usable]) usable++;
-    if (usable > 0 && fpvhip_inverse_submit(ctx_, (uint32_t)s, (uint32_t)usable, flags.data())) {
+    if (usable > 0 &&
+        (unshift >= 0 ? fpvhip_inverse_submit_raw(ctx_, (uint32_t)s, (uint32_t)usable, flags.data(), unshift,
+                                                  big_endian ? 1 : 0)
+                      : fpvhip_inverse_submit(ctx_, (uint32_t)s, (uint32_t)usable, flags.data()))) {
       Release(s);
       finish(prev);
       return FPV_FAILURE(fpvhip_last_error(ctx_));
@@ -467,6 +470,17 @@ bool RandomAccessDecoder::DecodeFrame(size_t index, uint16_t* frame) const {
 
 bool RandomAccessDecoder::DecodeFrames(const size_t* indices, size_t count,
                                        uint16_t* const* out, size_t threads) const {
+  return DecodeSharded(indices, count, reinterpret_cast<void* const*>(out), threads, -1, false);
+}
+
+bool RandomAccessDecoder::DecodeFramesRaw(const size_t* indices, size_t count, uint8_t* const* out,
+                                          int shift, bool big_endian, size_t threads) const {
+  if (shift < 0 || shift > 15) return FPV_FAILURE("shift must be 0..15");
+  return DecodeSharded(indices, count, reinterpret_cast<void* const*>(out), threads, shift, big_endian);
+}
+
+bool RandomAccessDecoder::DecodeSharded(const size_t* indices, size_t count, void* const* out,
+                                        size_t threads, int unshift, bool big_endian) const {
   if (!state_) return FPV_FAILURE("Init not called");
   std::vector<const uint8_t*> ins(count);
   std::vector<size_t> sizes(count);
@@ -479,7 +493,7 @@ bool RandomAccessDecoder::DecodeFrames(const size_t* indices, size_t count,
   if (shards < 2) {
     return st.engine->DecodeBatch(
         ins.data(), sizes.data(), count,
-        [&](size_t i, const uint16_t* px) { memcpy(out[i], px, bytes); }, threads);
+        [&](size_t i, const uint16_t* px) { memcpy(out[i], px, bytes); }, threads, unshift, big_endian);
   }
   {
     std::lock_guard<std::mutex> l(st.m);
@@ -498,7 +512,8 @@ bool RandomAccessDecoder::DecodeFrames(const size_t* indices, size_t count,
       InverseEngine* e = g == 0 ? st.engine.get() : st.more[g - 1].get();
       ok[g] = n == 0 || e->DecodeBatch(
                             ins.data() + first, sizes.data() + first, n,
-                            [&, first](size_t i, const uint16_t* px) { memcpy(out[first + i], px, bytes); }, th);
+                            [&, first](size_t i, const uint16_t* px) { memcpy(out[first + i], px, bytes); }, th,
+                            unshift, big_endian);
     });
   }
   for (auto& t : pool) t.join();

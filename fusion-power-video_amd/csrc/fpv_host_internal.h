@@ -77,8 +77,10 @@ class InverseEngine {
   // returned -- the order DecompressImage failures surface in the reference's
   // sequential loops (cc:914-936).
   typedef std::function<void(size_t index, const uint16_t* pixels)> Sink;
+  // unshift >= 0: UnextractFrame (cc:850-862) runs on the device before the copy back, the
+  // sink receives the raw file representation (pixel >> unshift, big- or little-endian).
   bool DecodeBatch(const uint8_t* const* ins, const size_t* sizes, size_t n,
-                   const Sink& sink, size_t threads);
+                   const Sink& sink, size_t threads, int unshift = -1, bool big_endian = false);
 
  private:
   InverseEngine() {}

@@ -74,6 +74,9 @@ hipError_t launch_interleave(const uint8_t* d_high, const uint8_t* d_low, uint16
 // pixels -> (px >> 8, px & 0xff) planes for npix_total pixels (multiple of 4, < 2^32).
 hipError_t launch_split_planes(const uint16_t* d_img, uint8_t* d_high, uint8_t* d_low,
                                size_t npix_total, hipStream_t s);
+// UnextractFrame (cc:850-862) in place on device pixels: value >> shift, byte order of the
+// raw file (big_endian != 0: swapped on this little-endian device).
+hipError_t launch_unextract(uint16_t* d_px, size_t npix_total, int shift, int big_endian, hipStream_t s);
 // Decoded delta image -> byte planes (decoder side, cc:337-338).
 hipError_t launch_split_decoded(const Geom& g, const uint16_t* d_img,
                                 uint8_t* d_high, uint8_t* d_low, hipStream_t s);

@@ -174,6 +174,29 @@ __global__ __launch_bounds__(kThreads) void k_split_decoded(
   *reinterpret_cast<uint32_t*>(low + i) = l4;
 }
 
+// UnextractFrame (cc:850-862) on the device, in place: decoded pixels -> the raw file
+// representation (value >> shift, stored little- or big-endian).  8 pixels per thread.
+__global__ __launch_bounds__(kThreads) void k_unextract(uint16_t* __restrict__ px, size_t npix_total,
+                                                       int shift, int swap) {
+  const size_t i = ((size_t)blockIdx.x * kThreads + threadIdx.x) * 8;
+  if (i >= npix_total) return;
+  const uint32_t keep = (0xffffu >> shift) * 0x00010001u;
+  auto conv = [&](uint32_t v) {
+    v = (v >> shift) & keep;                                  // both 16-bit lanes
+    return swap ? __builtin_amdgcn_perm(0, v, 0x02030001u) : v;  // bytes of each lane exchanged
+  };
+  if (i + 8 <= npix_total) {
+    uint4 v = *reinterpret_cast<const uint4*>(px + i);
+    v.x = conv(v.x); v.y = conv(v.y); v.z = conv(v.z); v.w = conv(v.w);
+    *reinterpret_cast<uint4*>(px + i) = v;
+  } else {
+    for (size_t k = i; k < npix_total; k++) {
+      const uint32_t u = (uint32_t)px[k] >> shift;
+      px[k] = (uint16_t)(swap ? ((u & 0xffu) << 8) | (u >> 8) : u);
+    }
+  }
+}
+
 // ------------------------------------------------------- forward predictor --
 //
 // The two predictor decisions of a frame depend on histograms of sampled
@@ -2171,6 +2194,13 @@ hipError_t launch_split_planes(const uint16_t* d_img, uint8_t* d_high, uint8_t* 
                                size_t npix_total, hipStream_t s) {
   k_split_decoded<<<(unsigned)((npix_total / 4 + kThreads - 1) / kThreads), kThreads, 0, s>>>(
       d_img, d_high, d_low, (uint32_t)npix_total);
+  return hipGetLastError();
+}
+
+hipError_t launch_unextract(uint16_t* d_px, size_t npix_total, int shift, int big_endian, hipStream_t s) {
+  if (npix_total == 0 || (shift == 0 && !big_endian)) return hipSuccess;  // already the raw little-endian values
+  k_unextract<<<(unsigned)((npix_total / 8 + kThreads) / kThreads), kThreads, 0, s>>>(d_px, npix_total, shift,
+                                                                                   big_endian ? 1 : 0);
   return hipGetLastError();
 }
 

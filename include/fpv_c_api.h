@@ -41,6 +41,11 @@ size_t fpvc_encode_stream(const uint16_t *frames, size_t nframes,
 long fpvc_decode_stream(const uint8_t *data, size_t size, uint16_t *frames_out,
                         size_t cap_frames, uint8_t *previews_out, int batched,
                         size_t threads);
+/* RandomAccessDecoder::DecodeFramesRaw over a whole stream: raw_out receives
+ * nframes * xs * ys * 2 bytes, the file representation UnextractFrame (h:32) produces.
+ * Returns the frame count or -1. */
+long fpvc_decode_stream_raw(const uint8_t *data, size_t size, uint8_t *raw_out,
+                            size_t cap_frames, int shift, int big_endian, size_t threads);
 /* StreamingDecoder (h:37-57) fed in pieces of `block` bytes (0 = everything in one
  * call).  Returns the frame count, or -(1 + frames delivered before the failure). */
 long fpvc_stream_decode(const uint8_t *data, size_t size, size_t block,

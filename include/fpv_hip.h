@@ -143,6 +143,13 @@ uint8_t *fpvhip_stage_plane(fpvhip_ctx *ctx, uint32_t slot, uint32_t k,
  */
 int fpvhip_inverse_submit(fpvhip_ctx *ctx, uint32_t slot, uint32_t nframes,
                           const uint8_t *flags);
+/*
+ * Same, with UnextractFrame (cc:850-862) applied on the device before the copy back: the
+ * 16-bit words fpvhip_inverse_wait hands out are the raw file representation
+ * (pixel >> unshift, stored big-endian when big_endian != 0).  unshift 0..15.
+ */
+int fpvhip_inverse_submit_raw(fpvhip_ctx *ctx, uint32_t slot, uint32_t nframes,
+                              const uint8_t *flags, int unshift, int big_endian);
 int fpvhip_inverse_wait(fpvhip_ctx *ctx, uint32_t slot,
                         const uint16_t **frames);
 /*

@@ -141,9 +141,16 @@ class RandomAccessDecoder {
   // batch is spread over `threads` workers.
   bool DecodeFrames(const size_t* indices, size_t count, uint16_t* const* out,
                     size_t threads = 8) const;
+  // Extension: the same with UnextractFrame (h:32) fused on the GPU -- out[i]
+  // receives xsize*ysize*2 raw bytes of frame indices[i], exactly what
+  // UnextractFrame(decoded, xsize, ysize, shift, big_endian, out[i]) would write.
+  bool DecodeFramesRaw(const size_t* indices, size_t count, uint8_t* const* out,
+                       int shift, bool big_endian, size_t threads = 8) const;
 
  private:
   struct State;
+  bool DecodeSharded(const size_t* indices, size_t count, void* const* out, size_t threads,
+                     int unshift, bool big_endian) const;
   size_t xsize_ = 0, ysize_ = 0;
   std::vector<size_t> frame_offsets_;
   const uint8_t* data_ = nullptr;

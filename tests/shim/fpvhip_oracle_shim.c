@@ -184,6 +184,17 @@ int fpvhip_inverse_submit(fpvhip_ctx *c, uint32_t slot, uint32_t n, const uint8_
   s->pending = n;
   return 0;
 }
+int fpvhip_inverse_submit_raw(fpvhip_ctx *c, uint32_t slot, uint32_t n, const uint8_t *flags,
+                              int unshift, int big_endian) {
+  slot_t *s = &c->slots[slot];
+  uint32_t k;
+  if (fpvhip_inverse_submit(c, slot, n, flags)) return -1;
+  for (k = 0; k < n; k++) {  /* in place: fpvo_unextract reads pixel i before it writes bytes 2i, 2i+1 */
+    uint16_t *px = s->pix + (size_t)k * c->npix;
+    fpvo_unextract(px, c->npix, unshift, big_endian, (uint8_t *)px);
+  }
+  return 0;
+}
 int fpvhip_inverse_planes_submit(fpvhip_ctx *c, uint32_t slot, uint32_t n, const uint8_t *flags) {
   slot_t *s = &c->slots[slot];
   uint32_t k;

@@ -96,3 +96,19 @@ def test_streaming_decoder_batched_calls(codec, synth):
     with pytest.raises(RuntimeError) as ei:
         codec.stream_decode(bad, 1280, 800, 20, block=0)
     assert np.array_equal(ei.value.delivered, want[:11])
+
+
+@pytest.mark.parametrize("shift,be", [(4, False), (4, True), (0, True), (8, False), (0, False)])
+def test_decode_frames_raw_fused_unextract(codec, synth, shift, be):
+    """K5: UnextractFrame (cc:850-862) fused on the GPU behind the inverse --
+    DecodeFramesRaw returns the bytes of the raw file the stream was made from."""
+    xs, ys = 320, 200
+    fr = synth.plasma_frames(10, xs, ys, bits=12 if shift == 4 else 16, seed=21)
+    if shift == 8:
+        fr = fr >> 8
+    src = fr.byteswap() if be else fr
+    fpv = codec.encode_stream(src, src[0], xs, ys, shift, be, threads=4)
+    raw = codec.decode_stream_raw(fpv, shift, be, threads=3)
+    assert np.array_equal(raw.reshape(-1), src.reshape(-1).view(np.uint8))
+    dec = codec.decode_stream(fpv)
+    assert np.array_equal(raw[3], codec.unextract(dec[3], xs, ys, shift, be))

@@ -148,6 +148,21 @@ def test_streaming_decoder_failure_order_in_batches(codec, synth, capfd):
     capfd.readouterr()
 
 
+def test_decode_frames_raw_equals_unextract(codec, oracle, synth):
+    """DecodeFramesRaw (UnextractFrame fused behind the inverse) gives the bytes the
+    host loop gives, for every shift / endianness the CLI accepts -- i.e. the file
+    the frames came from."""
+    for shift, be, bits in ((0, False, 16), (4, False, 12), (4, True, 12), (8, True, 8), (0, True, 16)):
+        fr = synth.noise_frames(9, 64, 48, seed=30 + shift) >> (16 - bits)
+        src = fr.byteswap() if be else fr
+        fpv = codec.encode_stream(src, src[0], 64, 48, shift, be, threads=2)
+        raw = codec.decode_stream_raw(fpv, shift, be, threads=3)
+        assert np.array_equal(raw.reshape(-1), src.reshape(-1).view(np.uint8)), (shift, be)
+        dec = codec.decode_stream(fpv)
+        for k in (0, 8):
+            assert np.array_equal(raw[k], oracle.unextract(dec[k], shift, be))
+
+
 def test_unextract_matches_oracle(codec, oracle, synth):
     img = synth.noise_frames(1, 64, 48, seed=8)[0]
     for shift, be in ((0, False), (4, False), (4, True), (8, True)):

@@ -23,10 +23,11 @@ REF      ?= /root/reference
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -I$(CSRC) -Wall -Wno-unused-value -Wno-unused-result
 CXXFLAGS := -std=c++14 -O2 -fPIC -Iinclude -I$(CSRC) -I$(BROTLI_I) -Wall -Wextra -pthread
 
-HOST_SRC := $(CSRC)/fpv_host.cc $(CSRC)/fpv_decoders.cc $(CSRC)/fpv_frame.cc $(CSRC)/fpv_c_api.cc
-HOST_HDR := include/fusion_power_video.h include/fpv_hip.h include/fpv_c_api.h $(CSRC)/fpv_host_internal.h $(CSRC)/fpv_frame_capi.inc
+HOST_SRC := $(CSRC)/fpv_host.cc $(CSRC)/fpv_decoders.cc $(CSRC)/fpv_frame.cc $(CSRC)/fpv_c_api.cc $(CSRC)/fpv_columnar.cc
+HOST_HDR := include/fusion_power_video.h include/fpv_hip.h include/fpv_c_api.h $(CSRC)/fpv_host_internal.h $(CSRC)/fpv_frame_capi.inc \
+            $(wildcard include/columnar_batch/*.h)
 
-all: product tools oracle shim refcli refcb
+all: product tools oracle shim refcli refcb columnar
 
 product: $(LIBDIR)/libfpvhip.so $(LIBDIR)/libfpv_amd.so
 
@@ -88,6 +89,29 @@ refcb:
 	@echo "refcb: $(REF) not present, skipped"
 endif
 
+# Native columnar batch adapter: our own test driver over the product library and over
+# the CPU test shim, and (where the upstream tree is present) the upstream columnar
+# tests compiled UNCHANGED against OUR columnar headers (symlinked so that their quoted
+# includes resolve to include/columnar_batch/).
+columnar: $(BINDIR)/columnar_driver tests/shim/columnar_driver_cpushim
+$(BINDIR)/columnar_driver: tests/columnar_driver.cc $(LIBDIR)/libfpv_amd.so $(wildcard include/columnar_batch/*.h)
+	@mkdir -p $(BINDIR)
+	$(CXX) -std=c++14 -O2 -Wall -Iinclude/columnar_batch $< -L$(LIBDIR) -lfpv_amd -lfpvhip -lpthread \
+	    -Wl,-rpath,'$$ORIGIN/../../$(LIBDIR)' -Wl,-rpath,$(ROCM_LIB) -o $@
+tests/shim/columnar_driver_cpushim: tests/columnar_driver.cc tests/shim/libfpv_amd_cpushim.so $(wildcard include/columnar_batch/*.h)
+	$(CXX) -std=c++14 -O2 -Wall -Iinclude/columnar_batch $< tests/shim/libfpv_amd_cpushim.so -lpthread \
+	    -Wl,-rpath,'$$ORIGIN' -o $@
+ifneq ($(wildcard $(REF)/columnar_batch/columnar_batch_decoder_test.cc),)
+columnar: $(BINDIR)/ref_cbtest_native_decoder $(BINDIR)/ref_cbtest_native_encoder
+build/refsrc_native/%.cc: $(REF)/columnar_batch/%.cc
+	@mkdir -p build/refsrc_native
+	ln -sf $< $@
+$(BINDIR)/ref_cbtest_native_%: build/refsrc_native/columnar_batch_%_test.cc $(LIBDIR)/libfpv_amd.so $(wildcard include/columnar_batch/*.h)
+	@mkdir -p $(BINDIR)
+	$(CXX) -std=c++17 -O2 -w -Iinclude/columnar_batch $< -L$(LIBDIR) -lfpv_amd -lfpvhip -lpthread \
+	    -Wl,-rpath,'$$ORIGIN/../../$(LIBDIR)' -Wl,-rpath,$(ROCM_LIB) -o $@
+endif
+
 oracle:
 	$(MAKE) -C oracle REF=$(REF)
 
@@ -113,8 +137,11 @@ build/asan/libfpv_amd_cpushim.so: tests/shim/fpvhip_oracle_shim.c oracle/fpv_ora
 	$(CXX) $(CXXFLAGS) -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -shared -Wl,-Bsymbolic $(HOST_SRC) build/asan/shim.o build/asan/oracle.o $(BROTLI) -o $@
 
 # ThreadSanitizer run of the threaded host paths (native driver; CPU only).
-tsan: build/tsan/driver
+tsan: build/tsan/driver build/tsan/columnar
 	TSAN_OPTIONS=halt_on_error=1 build/tsan/driver
+	TSAN_OPTIONS=halt_on_error=1 build/tsan/columnar
+build/tsan/columnar: tests/columnar_driver.cc build/tsan/driver
+	$(CXX) $(CXXFLAGS) -O1 -g -fsanitize=thread -Iinclude/columnar_batch tests/columnar_driver.cc $(HOST_SRC) build/tsan/shim.o build/tsan/oracle.o $(BROTLI) -o $@
 build/tsan/driver: tests/shim/tsan_driver.cc tests/shim/fpvhip_oracle_shim.c oracle/fpv_oracle.c $(HOST_SRC) $(HOST_HDR)
 	@mkdir -p build/tsan
 	gcc -std=c99 -O1 -g -fsanitize=thread -Iinclude -Ioracle -I$(BROTLI_I) -c tests/shim/fpvhip_oracle_shim.c -o build/tsan/shim.o
@@ -122,7 +149,7 @@ build/tsan/driver: tests/shim/tsan_driver.cc tests/shim/fpvhip_oracle_shim.c ora
 	$(CXX) $(CXXFLAGS) -O1 -g -fsanitize=thread tests/shim/tsan_driver.cc $(HOST_SRC) build/tsan/shim.o build/tsan/oracle.o $(BROTLI) -o $@
 
 clean:
-	rm -rf $(LIBDIR) build tests/shim/*.so tests/shim/*.o
+	rm -rf $(LIBDIR) build tests/shim/*.so tests/shim/*.o tests/shim/columnar_driver_cpushim
 	$(MAKE) -C oracle clean
 
-.PHONY: all product tools oracle shim refcli refcb asan tsan clean
+.PHONY: all product tools oracle shim refcli refcb columnar asan tsan clean

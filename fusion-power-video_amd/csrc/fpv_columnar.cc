@@ -1,0 +1,524 @@
+// fpv_columnar.cc -- the columnar batch adapter (include/columnar_batch/*.h) on the
+// MI355X path.  Upstream's adapter (columnar_batch/ of the reference, cb/...) drives
+// one Frame::Predict / Frame::Uncompress per frame from std::async tasks; here a batch
+// is the unit of GPU work in both directions:
+//
+//   encoder  PushFrame stages pixels into the pinned slot of the open batch; a full
+//            batch is ONE fpvhip_predict_submit (H2D, predictor kernels, D2H); a worker
+//            thread then Brotli-compresses the planes of its frames in parallel and
+//            appends them to the Batch columns in frame order
+//            (cb/columnar_batch_encoder.cc:24-57, 93-123; cb/columnar_batch.cc:65-87)
+//   decoder  the streams of a batch are Brotli-decoded in parallel straight into pinned
+//            staging, ONE fpvhip_inverse_submit inverts them, images go to the image
+//            processor in order (cb/columnar_batch_decoder.cc:51-95;
+//            cb/columnar_batch.cc:89-122)
+//
+// Everything that is not per-pixel work -- the column layout, queues, futures -- is
+// plain host code written for this design (no member-order race: threads start last).
+#include <brotli/decode.h>
+#include <brotli/encode.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
+
+#include "../../include/columnar_batch/columnar_batch.h"
+#include "../../include/columnar_batch/columnar_batch_decoder.h"
+#include "../../include/columnar_batch/columnar_batch_encoder.h"
+#include "fpv_hip.h"
+#include "fpv_host_internal.h"
+
+namespace fpvc {
+namespace columnarbatch {
+
+using namespace fpvc::internal;
+
+namespace {
+size_t RoundUp64(size_t v) { return (v + 63) & ~(size_t)63; }
+
+// Runs fn(i) for i in [0, n) on up to `threads` threads (the caller's included).
+template <typename F>
+void ParallelFor(size_t n, size_t threads, F fn) {
+  std::atomic<size_t> next(0);
+  auto work = [&] {
+    for (;;) {
+      const size_t i = next.fetch_add(1);
+      if (i >= n) return;
+      fn(i);
+    }
+  };
+  std::vector<std::thread> pool;
+  for (size_t t = 1; t < std::min(threads, n); t++) pool.emplace_back(work);
+  work();
+  for (auto& t : pool) t.join();
+}
+
+size_t WorkerThreads() {
+  return EnvSize("FPV_COLUMNAR_THREADS", std::max(1u, std::min(16u, std::thread::hardware_concurrency())));
+}
+}  // namespace
+
+// ============================================================= BatchSchema ==
+
+// cb/columnar_batch.cc:6-24: keeps a copy of the raw delta frame and its two planes as
+// Brotli streams (no preview, no clamped gradient).
+BatchSchema::BatchSchema(size_t xsize, size_t ysize, size_t shifted_left, Frame& uncompressed_delta_frame)
+    : xsize_(xsize), ysize_(ysize), shifted_left_(shifted_left), delta_frame_(uncompressed_delta_frame) {
+  const size_t cap = Frame::MaxCompressedPlaneSize(xsize, ysize);
+  delta_high_stream_.resize(cap);
+  delta_low_stream_.resize(cap);
+  size_t hs = cap, ls = cap, ps = 0;
+  uncompressed_delta_frame.CompressPredicted(&hs, delta_high_stream_.data(), &ls, delta_low_stream_.data(), &ps,
+                                             nullptr);
+  delta_high_stream_.resize(hs);
+  delta_low_stream_.resize(ls);
+}
+
+// =================================================================== Image ==
+
+Image::Image(int64_t timestamp, size_t xsize, size_t ysize, uint8_t bpp, Type type, std::vector<uint8_t>&& data)
+    : timestamp_(timestamp), xsize_(xsize), ysize_(ysize), bpp_(bpp), data_(std::move(data)), type_(type) {}
+
+// =================================================================== Batch ==
+
+Batch::Batch(size_t batch_size, SchemaPtr schema) : schema_(schema), batch_size_(batch_size), length_(0) {
+  previews_capacity_ = RoundUp64(batch_size * Frame::MaxCompressedPreviewSize(schema->xsize(), schema->ysize()));
+  plane_capacity_ = RoundUp64(batch_size * Frame::MaxCompressedPlaneSize(schema->xsize(), schema->ysize()));
+  const size_t ts_bytes = RoundUp64(batch_size * sizeof(int64_t));
+  const size_t flag_bytes = RoundUp64(batch_size);
+  const size_t off_bytes = RoundUp64((batch_size + 1) * sizeof(uint32_t));
+  capacity_[0] = previews_capacity_;
+  capacity_[1] = capacity_[2] = plane_capacity_;
+  // 64 spare bytes: the vector's storage itself is only 16-byte aligned
+  backing_buffer_.assign(ts_bytes + flag_bytes + 3 * off_bytes + previews_capacity_ + 2 * plane_capacity_ + 64, 0);
+  uint8_t* p = backing_buffer_.data();
+  p += (64 - reinterpret_cast<uintptr_t>(p) % 64) % 64;
+  timestamps_ = reinterpret_cast<int64_t*>(p);
+  p += ts_bytes;
+  flags_ = p;
+  p += flag_bytes;
+  for (int c = 0; c < 3; c++) {
+    offsets_[c] = reinterpret_cast<uint32_t*>(p);
+    p += off_bytes;
+  }
+  for (int c = 0; c < 3; c++) {
+    columns_[c] = p;
+    p += capacity_[c];
+  }
+  Reset();
+}
+
+void Batch::Reset() {
+  length_ = 0;
+  for (int c = 0; c < 3; c++) offsets_[c][0] = 0;
+}
+
+bool Batch::AppendCompressed(int64_t timestamp, uint8_t flags, const uint8_t* high, size_t high_size,
+                             const uint8_t* low, size_t low_size, const uint8_t* preview, size_t preview_size) {
+  if (length_ >= batch_size_) return false;
+  const uint8_t* src[3] = {preview, high, low};
+  const size_t n[3] = {preview_size, high_size, low_size};
+  for (int c = 0; c < 3; c++)
+    if (offsets_[c][length_] + n[c] > capacity_[c]) return false;
+  timestamps_[length_] = timestamp;
+  flags_[length_] = flags;
+  for (int c = 0; c < 3; c++) {
+    if (n[c]) memcpy(columns_[c] + offsets_[c][length_], src[c], n[c]);
+    offsets_[c][length_ + 1] = offsets_[c][length_] + (uint32_t)n[c];
+  }
+  length_++;
+  return true;
+}
+
+// cb/columnar_batch.cc:65-87
+bool Batch::AppendPredicted(Frame predicted_frame) {
+  if (length_ >= batch_size_) return false;
+  size_t n[3];
+  for (int c = 0; c < 3; c++) n[c] = capacity_[c] - offsets_[c][length_];
+  predicted_frame.CompressPredicted(&n[1], columns_[1] + offsets_[1][length_], &n[2], columns_[2] + offsets_[2][length_],
+                                    &n[0], columns_[0] + offsets_[0][length_]);
+  timestamps_[length_] = predicted_frame.timestamp();
+  flags_[length_] = predicted_frame.flags();
+  for (int c = 0; c < 3; c++) offsets_[c][length_ + 1] = offsets_[c][length_] + (uint32_t)n[c];
+  length_++;
+  return true;
+}
+
+const uint8_t* Batch::stream(size_t index, int which, size_t* size) const {
+  *size = offsets_[which][index + 1] - offsets_[which][index];
+  return columns_[which] + offsets_[which][index];
+}
+
+// cb/columnar_batch.cc:89-122: one image on its own, through Frame::Uncompress.
+Image Batch::ExtractImage(size_t index, Image::Type type) {
+  size_t n;
+  std::vector<uint8_t> high, low, preview;
+  uint8_t flags = flags_[index];
+  uint8_t state = FrameState::COMPRESSED | FrameState::DELTA_PREDICTED | FrameState::CG_PREDICTED;
+  if (type == Image::PREVIEW) {
+    const uint8_t* p = stream(index, 0, &n);
+    preview.assign(p, p + n);
+    if (!preview.empty()) state |= FrameState::PREVIEW_GENERATED;
+  } else {
+    const uint8_t* p = stream(index, 1, &n);
+    high.assign(p, p + n);
+    if (type == Image::FULL) {
+      p = stream(index, 2, &n);
+      low.assign(p, p + n);
+    } else {
+      flags |= FrameFlags::NO_LOW_BYTES;
+    }
+  }
+  Frame frame(schema_->xsize(), schema_->ysize(), flags, state, std::move(high), std::move(low), std::move(preview),
+              timestamps_[index]);
+  frame.Uncompress(schema_->delta_frame());
+  if (type == Image::PREVIEW)
+    return Image(frame.timestamp(), frame.xsize() / 4, frame.ysize() / 4, 8, type, frame.MoveOutPreview());
+  if (type == Image::MSB8) return Image(frame.timestamp(), frame.xsize(), frame.ysize(), 8, type, frame.MoveOutHigh());
+  const size_t npix = frame.xsize() * frame.ysize();
+  std::vector<uint8_t> data(2 * npix);
+  const std::vector<uint8_t>&h = frame.high(), &l = frame.low();
+  for (size_t i = 0; i < npix; i++) {
+    data[2 * i] = i < l.size() ? l[i] : 0;
+    data[2 * i + 1] = h[i];
+  }
+  return Image(frame.timestamp(), frame.xsize(), frame.ysize(), (uint8_t)(16 - schema_->shiftedLeft()), type,
+               std::move(data));
+}
+
+// ==================================================== ColumnarBatchEncoder ==
+
+struct ColumnarBatchEncoder::Impl {
+  struct Pending {  // a batch on the GPU
+    uint32_t slot;
+    std::vector<int64_t> ts;
+  };
+  const size_t xs, ys, npix, npv;
+  const int shift;
+  const bool big_endian;
+  const size_t per_batch;
+  BatchProcessor processor;
+
+  fpvhip_ctx* ctx = nullptr;
+  SchemaPtr schema;
+
+  std::mutex m;
+  std::condition_variable cv;
+  bool closing = false, closed = false;
+  char slot_busy[2] = {0, 0};
+  int open_slot = -1;            // slot being filled by PushFrame
+  std::vector<int64_t> open_ts;  // timestamps of the frames staged in it
+  std::deque<Pending> submitted;
+  std::vector<BatchPtr> spare;   // returned by ReturnProcessedBatch
+  int64_t latest_stored = -1;
+  std::promise<int64_t> closing_promise;
+  std::shared_future<int64_t> closing_future;
+  std::thread worker;
+
+  Impl(size_t x, size_t y, int s, bool be, BatchProcessor p, int n)
+      : xs(x), ys(y), npix(x * y), npv((x / 4) * (y / 4)), shift(s), big_endian(be),
+        per_batch((size_t)std::max(1, n)), processor(std::move(p)), closing_future(closing_promise.get_future()) {
+    const int device = DeviceList()[0];
+    ctx = AcquireEncoderCtx(device, (uint32_t)xs, (uint32_t)ys, shift, big_endian, (uint32_t)per_batch, 2);
+    if (!ctx) Fatal("ColumnarBatchEncoder", fpvhip_last_error(nullptr));
+    worker = std::thread(&Impl::Work, this);  // last: everything it touches exists
+  }
+
+  ~Impl() {
+    if (worker.joinable()) worker.join();
+    if (ctx) ReleaseEncoderCtx(ctx);
+  }
+
+  void SubmitOpenLocked() {  // m held, open_slot has frames
+    if (fpvhip_predict_submit(ctx, (uint32_t)open_slot, (uint32_t)open_ts.size(), 1))
+      Fatal("fpvhip_predict_submit", fpvhip_last_error(ctx));
+    submitted.push_back(Pending{(uint32_t)open_slot, std::move(open_ts)});
+    open_ts.clear();
+    open_slot = -1;
+    cv.notify_all();
+  }
+
+  BatchPtr TakeBatch() {
+    std::lock_guard<std::mutex> l(m);
+    if (!spare.empty()) {
+      BatchPtr b = spare.back();
+      spare.pop_back();
+      return b;
+    }
+    return std::make_shared<Batch>(per_batch, schema);
+  }
+
+  void Work() {
+    const size_t threads = WorkerThreads();
+    for (;;) {
+      Pending p;
+      {
+        std::unique_lock<std::mutex> l(m);
+        cv.wait(l, [&] { return !submitted.empty() || closing; });
+        if (submitted.empty()) break;  // closing and drained
+        p = std::move(submitted.front());
+        submitted.pop_front();
+      }
+      const uint8_t *high, *low, *pv, *flags;
+      if (fpvhip_predict_wait(ctx, p.slot, &high, &low, &pv, &flags)) Fatal("fpvhip_predict_wait", fpvhip_last_error(ctx));
+      const size_t n = p.ts.size();
+      // Brotli of the 3 planes of every frame, frames in parallel (cc:643-688 per plane)
+      std::vector<std::vector<uint8_t>> sh(n), sl(n), sp(n);
+      // one task per plane (low planes first: they are the expensive ones), so that a
+      // batch of few frames still spreads over all threads
+      ParallelFor(3 * n, threads, [&](size_t t) {
+        const size_t k = t % n, which = t / n;
+        if (which == 0) {
+          if (!(flags[k] & NO_LOW_BYTES) && !BrotliAppend(low + k * npix, npix, &sl[k])) Fatal("Brotli", "low plane");
+        } else if (which == 1) {
+          if (!BrotliAppend(high + k * npix, npix, &sh[k])) Fatal("Brotli", "high plane");
+        } else if (!BrotliAppend(pv + k * npv, npv, &sp[k])) {
+          Fatal("Brotli", "preview plane");
+        }
+      });
+      BatchPtr batch = TakeBatch();
+      for (size_t k = 0; k < n; k++)
+        if (!batch->AppendCompressed(p.ts[k], flags[k], sh[k].data(), sh[k].size(), sl[k].data(), sl[k].size(),
+                                     sp[k].data(), sp[k].size()))
+          Fatal("ColumnarBatchEncoder", "batch column overflow");
+      {
+        std::lock_guard<std::mutex> l(m);
+        slot_busy[p.slot] = 0;  // the pinned planes have been consumed
+        latest_stored = batch->LatestTimestamp();
+      }
+      cv.notify_all();
+      processor(batch);  // on this thread, one batch at a time, in order
+    }
+    // cb/columnar_batch_encoder.cc:82-91: nothing left to flush -> a null batch
+    bool announce_empty;
+    int64_t last;
+    {
+      std::lock_guard<std::mutex> l(m);
+      announce_empty = flushed_partial == false;
+      last = latest_stored;
+    }
+    if (announce_empty) processor(nullptr);
+    closing_promise.set_value(last);
+  }
+  bool flushed_partial = false;  // Close submitted a partial batch
+};
+
+ColumnarBatchEncoder::ColumnarBatchEncoder(size_t xsize, size_t ysize, int shift_to_left_align, bool big_endian,
+                                           BatchProcessor batch_processor, int frames_per_batch)
+    : impl_(new Impl(xsize, ysize, shift_to_left_align, big_endian, std::move(batch_processor), frames_per_batch)) {}
+
+ColumnarBatchEncoder::~ColumnarBatchEncoder() {
+  Close();
+  impl_.reset();
+}
+
+std::future<void*> ColumnarBatchEncoder::PushFrame(uint64_t timestamp, uint16_t* frame, void* info) {
+  Impl& s = *impl_;
+  std::unique_lock<std::mutex> l(s.m);
+  if (s.closing) return std::future<void*>();
+  if (!s.schema) {  // the first frame is the delta frame of the stream (and an ordinary frame too)
+    l.unlock();
+    Frame delta(s.xs, s.ys, frame, s.shift, s.big_endian, (int64_t)timestamp);
+    SchemaPtr schema = std::make_shared<BatchSchema>(s.xs, s.ys, (size_t)s.shift, delta);
+    if (fpvhip_set_delta_raw(s.ctx, frame)) Fatal("fpvhip_set_delta_raw", fpvhip_last_error(s.ctx));
+    l.lock();
+    s.schema = schema;
+  }
+  if (s.open_slot < 0) {
+    s.cv.wait(l, [&] { return !s.slot_busy[0] || !s.slot_busy[1]; });
+    s.open_slot = s.slot_busy[0] ? 1 : 0;
+    s.slot_busy[s.open_slot] = 1;
+  }
+  const int slot = s.open_slot;
+  const size_t k = s.open_ts.size();
+  l.unlock();
+  uint16_t* dst = fpvhip_stage_in(s.ctx, (uint32_t)slot, (uint32_t)k);
+  if (!dst) Fatal("fpvhip_stage_in", fpvhip_last_error(s.ctx));
+  memcpy(dst, frame, s.npix * 2);  // the caller's buffer is free from here on
+  l.lock();
+  s.open_ts.push_back((int64_t)timestamp);
+  if (s.open_ts.size() == s.per_batch) s.SubmitOpenLocked();
+  l.unlock();
+  std::promise<void*> done;
+  done.set_value(info);
+  return done.get_future();
+}
+
+void ColumnarBatchEncoder::ReturnProcessedBatch(BatchPtr processed) {
+  if (!processed) return;
+  processed->Reset();
+  std::lock_guard<std::mutex> l(impl_->m);
+  impl_->spare.push_back(processed);
+}
+
+std::shared_future<int64_t> ColumnarBatchEncoder::Close() {
+  Impl& s = *impl_;
+  {
+    std::lock_guard<std::mutex> l(s.m);
+    if (!s.closed) {
+      s.closed = true;
+      if (s.open_slot >= 0 && !s.open_ts.empty()) {
+        s.flushed_partial = true;
+        s.SubmitOpenLocked();
+      }
+      s.closing = true;
+    }
+  }
+  s.cv.notify_all();
+  return s.closing_future;
+}
+
+// ==================================================== ColumnarBatchDecoder ==
+
+struct ColumnarBatchDecoder::Impl {
+  struct Job {
+    BatchPtr batch;
+    std::promise<BatchPtr> done;
+  };
+  const Image::Type type;
+  const bool unshift;
+  ImageProcessor processor;
+
+  std::mutex m;
+  std::condition_variable cv;
+  bool closing = false, closed = false;
+  std::deque<Job> queue;
+  SchemaPtr schema;
+  std::shared_ptr<InverseEngine> engine;  // full-size or preview geometry, created with the first batch
+  int64_t latest = -1;
+  std::promise<int64_t> closing_promise;
+  std::shared_future<int64_t> closing_future;
+  std::thread worker;
+
+  Impl(Image::Type t, bool u, ImageProcessor p)
+      : type(t), unshift(u), processor(std::move(p)), closing_future(closing_promise.get_future()) {
+    worker = std::thread(&Impl::Work, this);  // last: everything it touches exists
+  }
+  ~Impl() {
+    if (worker.joinable()) worker.join();
+  }
+
+  bool Prepare(const Batch& batch) {
+    if (engine) return true;
+    BatchSchema& sc = *batch.schema();
+    const bool pv = type == Image::PREVIEW;
+    const size_t xs = pv ? sc.xsize() / 4 : sc.xsize(), ys = pv ? sc.ysize() / 4 : sc.ysize();
+    const uint32_t per = (uint32_t)std::max<size_t>(1, batch.length());
+    engine = InverseEngine::Create(xs, ys, std::max(per, 1u), 2, DeviceList()[0]);
+    if (!engine) return false;
+    capacity = per;
+    if (!pv) {  // decoded delta frame = the schema's raw planes (cb/columnar_batch.cc:111)
+      Frame& d = sc.delta_frame();
+      const std::vector<uint8_t>&h = d.high(), &l = d.low();
+      std::vector<uint16_t> delta16(xs * ys);
+      for (size_t i = 0; i < delta16.size(); i++)
+        delta16[i] = (uint16_t)((h[i] << 8) | (i < l.size() ? l[i] : 0));
+      if (!engine->SetDelta(delta16.data())) return false;
+    }
+    return true;
+  }
+  uint32_t capacity = 0;
+
+  void DecodeBatch(Batch& batch) {
+    const size_t n = batch.length();
+    if (n == 0) return;
+    if (!Prepare(batch)) Fatal("ColumnarBatchDecoder", "no GPU decoder");
+    BatchSchema& sc = *batch.schema();
+    const bool pv = type == Image::PREVIEW;
+    const size_t xs = pv ? sc.xsize() / 4 : sc.xsize(), ys = pv ? sc.ysize() / 4 : sc.ysize(), npix = xs * ys;
+    const int shr = (unshift && type == Image::FULL) ? (int)sc.shiftedLeft() : 0;
+    std::vector<InverseEngine::PlaneStreams> in(n);
+    for (size_t i = 0; i < n; i++) {
+      InverseEngine::PlaneStreams& p = in[i];
+      const uint8_t f = batch.flags(i);
+      if (pv) {  // the preview is its own little image: CG flag only, no low plane, no delta
+        p.high = batch.stream(i, 0, &p.high_size);
+        p.flags = (uint8_t)((f & USE_CG) | NO_LOW_BYTES);
+      } else {
+        p.high = batch.stream(i, 1, &p.high_size);
+        p.low = batch.stream(i, 2, &p.low_size);
+        p.flags = type == Image::MSB8 ? (uint8_t)(f | NO_LOW_BYTES) : f;
+        if (p.flags & NO_LOW_BYTES) p.low = nullptr, p.low_size = 0;
+      }
+    }
+    const size_t threads = WorkerThreads();
+    const bool ok = engine->DecodePlanesBatch(in.data(), n, [&](size_t i, const uint16_t* px) {
+      std::vector<uint8_t> data;
+      uint8_t bpp = 8;
+      if (type == Image::FULL) {
+        data.resize(2 * npix);
+        uint16_t* out = reinterpret_cast<uint16_t*>(data.data());
+        if (shr > 0) for (size_t k = 0; k < npix; k++) out[k] = (uint16_t)(px[k] >> shr);
+        else memcpy(out, px, 2 * npix);
+        bpp = (uint8_t)(16 - sc.shiftedLeft());
+      } else {  // PREVIEW, MSB8: the high bytes
+        data.resize(npix);
+        for (size_t k = 0; k < npix; k++) data[k] = (uint8_t)(px[k] >> 8);
+      }
+      processor(Image(batch.timestamp(i), xs, ys, bpp, type, std::move(data)));
+    }, threads);
+    if (!ok) Fatal("ColumnarBatchDecoder", "decoding a batch failed");
+  }
+
+  void Work() {
+    for (;;) {
+      Job job;
+      {
+        std::unique_lock<std::mutex> l(m);
+        cv.wait(l, [&] { return !queue.empty() || closing; });
+        if (queue.empty()) break;
+        job = std::move(queue.front());
+        queue.pop_front();
+      }
+      DecodeBatch(*job.batch);
+      {
+        std::lock_guard<std::mutex> l(m);
+        if (!job.batch->Empty()) latest = job.batch->LatestTimestamp();
+      }
+      job.done.set_value(job.batch);
+    }
+    closing_promise.set_value(latest);
+  }
+};
+
+ColumnarBatchDecoder::ColumnarBatchDecoder(Image::Type type, bool unshift, ImageProcessor image_processor)
+    : impl_(new Impl(type, unshift, std::move(image_processor))) {}
+
+ColumnarBatchDecoder::~ColumnarBatchDecoder() {
+  Close();
+  impl_.reset();
+}
+
+std::future<BatchPtr> ColumnarBatchDecoder::PushBatch(BatchPtr batch) {
+  Impl& s = *impl_;
+  std::future<BatchPtr> fut;
+  {
+    std::lock_guard<std::mutex> l(s.m);
+    if (!batch || s.closing) return std::future<BatchPtr>();
+    if (!s.schema) s.schema = batch->schema();
+    if (s.schema.get() != batch->schema().get()) return std::future<BatchPtr>();
+    Impl::Job job;
+    job.batch = batch;
+    fut = job.done.get_future();
+    s.queue.push_back(std::move(job));
+  }
+  s.cv.notify_all();
+  return fut;
+}
+
+std::shared_future<int64_t> ColumnarBatchDecoder::Close() {
+  Impl& s = *impl_;
+  {
+    std::lock_guard<std::mutex> l(s.m);
+    s.closing = true;
+  }
+  s.cv.notify_all();
+  return s.closing_future;
+}
+
+}  // namespace columnarbatch
+}  // namespace fpvc

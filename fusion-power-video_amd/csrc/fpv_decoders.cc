@@ -173,8 +173,37 @@ bool InverseEngine::Decode(const uint8_t* in, size_t size, const uint16_t** fram
   return true;
 }
 
+bool InverseEngine::UnpackPlanes(const PlaneStreams& p, uint32_t slot, uint32_t k, uint8_t* flags) {
+  size_t pos = 0, got = 0;
+  uint8_t f = p.flags;
+  if ((f & USE_DELTA) && !has_delta_) return FPV_FAILURE("delta frame not given");
+  if (!p.low || p.low_size == 0) f |= NO_LOW_BYTES;
+  if (!(f & NO_LOW_BYTES)) {
+    if (!BrotliInto(p.low, p.low_size, &pos, fpvhip_stage_plane(ctx_, slot, k, 1), npix_, &got) || got != npix_)
+      return FPV_FAILURE("brotli decompression of a low plane failed");
+  }
+  pos = 0;
+  if (!BrotliInto(p.high, p.high_size, &pos, fpvhip_stage_plane(ctx_, slot, k, 0), npix_, &got) || got != npix_)
+    return FPV_FAILURE("brotli decompression of a high plane failed");
+  *flags = f;
+  return true;
+}
+
 bool InverseEngine::DecodeBatch(const uint8_t* const* ins, const size_t* sizes, size_t n,
                                 const Sink& sink, size_t threads, int unshift, bool big_endian) {
+  return RunBatches(
+      n, [&](size_t i, uint32_t slot, uint32_t k, uint8_t* flags) { return Unpack(ins[i], sizes[i], slot, k, flags); },
+      sink, threads, unshift, big_endian);
+}
+
+bool InverseEngine::DecodePlanesBatch(const PlaneStreams* images, size_t n, const Sink& sink, size_t threads) {
+  return RunBatches(
+      n, [&](size_t i, uint32_t slot, uint32_t k, uint8_t* flags) { return UnpackPlanes(images[i], slot, k, flags); },
+      sink, threads, -1, false);
+}
+
+bool InverseEngine::RunBatches(size_t n, const Unpacker& unpack, const Sink& sink, size_t threads, int unshift,
+                               bool big_endian) {
   if (threads == 0) threads = 1;
   // Two slots alternate: while the GPU inverts batch g, the host threads
   // Brotli-decode batch g+1 into the other slot.
@@ -209,7 +238,7 @@ bool InverseEngine::DecodeBatch(const uint8_t* const* ins, const size_t* sizes, 
       for (;;) {
         size_t i = next.fetch_add(1);
         if (i >= count) return;
-        good[i] = Unpack(ins[first + i], sizes[first + i], (uint32_t)s, (uint32_t)i, &flags[i]);
+        good[i] = unpack(first + i, (uint32_t)s, (uint32_t)i, &flags[i]);
       }
     };
     const size_t nt = std::min(threads, count);

@@ -82,10 +82,26 @@ class InverseEngine {
   bool DecodeBatch(const uint8_t* const* ins, const size_t* sizes, size_t n,
                    const Sink& sink, size_t threads, int unshift = -1, bool big_endian = false);
 
+  // The same for images whose planes are separate Brotli streams (columnar batches):
+  // low == nullptr or NO_LOW_BYTES in flags means "no low plane".
+  struct PlaneStreams {
+    const uint8_t* high = nullptr;
+    size_t high_size = 0;
+    const uint8_t* low = nullptr;
+    size_t low_size = 0;
+    uint8_t flags = 0;
+  };
+  bool DecodePlanesBatch(const PlaneStreams* images, size_t n, const Sink& sink, size_t threads);
+
  private:
   InverseEngine() {}
   int AcquireSlot();
   bool Unpack(const uint8_t* in, size_t size, uint32_t slot, uint32_t k, uint8_t* flags);
+  bool UnpackPlanes(const PlaneStreams& p, uint32_t slot, uint32_t k, uint8_t* flags);
+  // Unpacker: (image index, slot, position in the batch, out flags) -> ok
+  typedef std::function<bool(size_t, uint32_t, uint32_t, uint8_t*)> Unpacker;
+  bool RunBatches(size_t n, const Unpacker& unpack, const Sink& sink, size_t threads, int unshift,
+                  bool big_endian);
 
   fpvhip_ctx* ctx_ = nullptr;
   size_t npix_ = 0;

@@ -67,39 +67,37 @@ size_t WorkerThreads() {
 // cb/columnar_batch.cc:6-24: keeps a copy of the raw delta frame and its two planes as
 // Brotli streams (no preview, no clamped gradient).
 BatchSchema::BatchSchema(size_t xsize, size_t ysize, size_t shifted_left, Frame& uncompressed_delta_frame)
-    : xsize_(xsize), ysize_(ysize), shifted_left_(shifted_left), delta_frame_(uncompressed_delta_frame) {
+    : delta_(uncompressed_delta_frame), width_(xsize), height_(ysize), left_shift_(shifted_left) {
   const size_t cap = Frame::MaxCompressedPlaneSize(xsize, ysize);
-  delta_high_stream_.resize(cap);
-  delta_low_stream_.resize(cap);
-  size_t hs = cap, ls = cap, ps = 0;
-  uncompressed_delta_frame.CompressPredicted(&hs, delta_high_stream_.data(), &ls, delta_low_stream_.data(), &ps,
-                                             nullptr);
-  delta_high_stream_.resize(hs);
-  delta_low_stream_.resize(ls);
+  size_t sizes[2] = {cap, cap}, no_preview = 0;
+  for (auto& v : delta_streams_) v.resize(cap);
+  uncompressed_delta_frame.CompressPredicted(&sizes[0], delta_streams_[0].data(), &sizes[1], delta_streams_[1].data(),
+                                             &no_preview, nullptr);
+  for (int k = 0; k < 2; k++) delta_streams_[k].resize(sizes[k]);
 }
 
 // =================================================================== Image ==
 
 Image::Image(int64_t timestamp, size_t xsize, size_t ysize, uint8_t bpp, Type type, std::vector<uint8_t>&& data)
-    : timestamp_(timestamp), xsize_(xsize), ysize_(ysize), bpp_(bpp), data_(std::move(data)), type_(type) {}
+    : bytes_(std::move(data)), when_(timestamp), width_(xsize), height_(ysize), kind_(type), bits_(bpp) {}
 
 // =================================================================== Batch ==
 
-Batch::Batch(size_t batch_size, SchemaPtr schema) : schema_(schema), batch_size_(batch_size), length_(0) {
-  previews_capacity_ = RoundUp64(batch_size * Frame::MaxCompressedPreviewSize(schema->xsize(), schema->ysize()));
-  plane_capacity_ = RoundUp64(batch_size * Frame::MaxCompressedPlaneSize(schema->xsize(), schema->ysize()));
+Batch::Batch(size_t batch_size, SchemaPtr schema) : schema_(schema), rows_(batch_size), count_(0) {
+  const size_t previews_capacity_ = RoundUp64(batch_size * Frame::MaxCompressedPreviewSize(schema->xsize(), schema->ysize()));
+  const size_t plane_capacity_ = RoundUp64(batch_size * Frame::MaxCompressedPlaneSize(schema->xsize(), schema->ysize()));
   const size_t ts_bytes = RoundUp64(batch_size * sizeof(int64_t));
   const size_t flag_bytes = RoundUp64(batch_size);
   const size_t off_bytes = RoundUp64((batch_size + 1) * sizeof(uint32_t));
   capacity_[0] = previews_capacity_;
   capacity_[1] = capacity_[2] = plane_capacity_;
   // 64 spare bytes: the vector's storage itself is only 16-byte aligned
-  backing_buffer_.assign(ts_bytes + flag_bytes + 3 * off_bytes + previews_capacity_ + 2 * plane_capacity_ + 64, 0);
-  uint8_t* p = backing_buffer_.data();
+  storage_.assign(ts_bytes + flag_bytes + 3 * off_bytes + previews_capacity_ + 2 * plane_capacity_ + 64, 0);
+  uint8_t* p = storage_.data();
   p += (64 - reinterpret_cast<uintptr_t>(p) % 64) % 64;
-  timestamps_ = reinterpret_cast<int64_t*>(p);
+  stamps_ = reinterpret_cast<int64_t*>(p);
   p += ts_bytes;
-  flags_ = p;
+  flag_col_ = p;
   p += flag_bytes;
   for (int c = 0; c < 3; c++) {
     offsets_[c] = reinterpret_cast<uint32_t*>(p);
@@ -113,38 +111,38 @@ Batch::Batch(size_t batch_size, SchemaPtr schema) : schema_(schema), batch_size_
 }
 
 void Batch::Reset() {
-  length_ = 0;
+  count_ = 0;
   for (int c = 0; c < 3; c++) offsets_[c][0] = 0;
 }
 
 bool Batch::AppendCompressed(int64_t timestamp, uint8_t flags, const uint8_t* high, size_t high_size,
                              const uint8_t* low, size_t low_size, const uint8_t* preview, size_t preview_size) {
-  if (length_ >= batch_size_) return false;
+  if (count_ >= rows_) return false;
   const uint8_t* src[3] = {preview, high, low};
   const size_t n[3] = {preview_size, high_size, low_size};
   for (int c = 0; c < 3; c++)
-    if (offsets_[c][length_] + n[c] > capacity_[c]) return false;
-  timestamps_[length_] = timestamp;
-  flags_[length_] = flags;
+    if (offsets_[c][count_] + n[c] > capacity_[c]) return false;
+  stamps_[count_] = timestamp;
+  flag_col_[count_] = flags;
   for (int c = 0; c < 3; c++) {
-    if (n[c]) memcpy(columns_[c] + offsets_[c][length_], src[c], n[c]);
-    offsets_[c][length_ + 1] = offsets_[c][length_] + (uint32_t)n[c];
+    if (n[c]) memcpy(columns_[c] + offsets_[c][count_], src[c], n[c]);
+    offsets_[c][count_ + 1] = offsets_[c][count_] + (uint32_t)n[c];
   }
-  length_++;
+  count_++;
   return true;
 }
 
 // cb/columnar_batch.cc:65-87
 bool Batch::AppendPredicted(Frame predicted_frame) {
-  if (length_ >= batch_size_) return false;
+  if (count_ >= rows_) return false;
   size_t n[3];
-  for (int c = 0; c < 3; c++) n[c] = capacity_[c] - offsets_[c][length_];
-  predicted_frame.CompressPredicted(&n[1], columns_[1] + offsets_[1][length_], &n[2], columns_[2] + offsets_[2][length_],
-                                    &n[0], columns_[0] + offsets_[0][length_]);
-  timestamps_[length_] = predicted_frame.timestamp();
-  flags_[length_] = predicted_frame.flags();
-  for (int c = 0; c < 3; c++) offsets_[c][length_ + 1] = offsets_[c][length_] + (uint32_t)n[c];
-  length_++;
+  for (int c = 0; c < 3; c++) n[c] = capacity_[c] - offsets_[c][count_];
+  predicted_frame.CompressPredicted(&n[1], columns_[1] + offsets_[1][count_], &n[2], columns_[2] + offsets_[2][count_],
+                                    &n[0], columns_[0] + offsets_[0][count_]);
+  stamps_[count_] = predicted_frame.timestamp();
+  flag_col_[count_] = predicted_frame.flags();
+  for (int c = 0; c < 3; c++) offsets_[c][count_ + 1] = offsets_[c][count_] + (uint32_t)n[c];
+  count_++;
   return true;
 }
 
@@ -157,7 +155,7 @@ const uint8_t* Batch::stream(size_t index, int which, size_t* size) const {
 Image Batch::ExtractImage(size_t index, Image::Type type) {
   size_t n;
   std::vector<uint8_t> high, low, preview;
-  uint8_t flags = flags_[index];
+  uint8_t flags = flag_col_[index];
   uint8_t state = FrameState::COMPRESSED | FrameState::DELTA_PREDICTED | FrameState::CG_PREDICTED;
   if (type == Image::PREVIEW) {
     const uint8_t* p = stream(index, 0, &n);
@@ -174,7 +172,7 @@ Image Batch::ExtractImage(size_t index, Image::Type type) {
     }
   }
   Frame frame(schema_->xsize(), schema_->ysize(), flags, state, std::move(high), std::move(low), std::move(preview),
-              timestamps_[index]);
+              stamps_[index]);
   frame.Uncompress(schema_->delta_frame());
   if (type == Image::PREVIEW)
     return Image(frame.timestamp(), frame.xsize() / 4, frame.ysize() / 4, 8, type, frame.MoveOutPreview());

@@ -194,6 +194,7 @@ struct ColumnarBatchEncoder::Impl {
   struct Pending {  // a batch on the GPU
     uint32_t slot;
     std::vector<int64_t> ts;
+    uint64_t seq;  // batches leave in the order they were submitted in
   };
   const size_t xs, ys, npix, npv;
   const int shift;
@@ -207,7 +208,10 @@ struct ColumnarBatchEncoder::Impl {
   std::mutex m;
   std::condition_variable cv;
   bool closing = false, closed = false;
-  char slot_busy[2] = {0, 0};
+  static constexpr int kSlots = 3, kWorkers = 2;  // one slot filling, two batches in the workers
+  char slot_busy[kSlots] = {0, 0, 0};
+  uint64_t next_seq = 0, next_emit = 0;
+  int workers_left = kWorkers;
   int open_slot = -1;            // slot being filled by PushFrame
   std::vector<int64_t> open_ts;  // timestamps of the frames staged in it
   std::deque<Pending> submitted;
@@ -215,26 +219,27 @@ struct ColumnarBatchEncoder::Impl {
   int64_t latest_stored = -1;
   std::promise<int64_t> closing_promise;
   std::shared_future<int64_t> closing_future;
-  std::thread worker;
+  std::thread workers[kWorkers];
 
   Impl(size_t x, size_t y, int s, bool be, BatchProcessor p, int n)
       : xs(x), ys(y), npix(x * y), npv((x / 4) * (y / 4)), shift(s), big_endian(be),
         per_batch((size_t)std::max(1, n)), processor(std::move(p)), closing_future(closing_promise.get_future()) {
     const int device = DeviceList()[0];
-    ctx = AcquireEncoderCtx(device, (uint32_t)xs, (uint32_t)ys, shift, big_endian, (uint32_t)per_batch, 2);
+    ctx = AcquireEncoderCtx(device, (uint32_t)xs, (uint32_t)ys, shift, big_endian, (uint32_t)per_batch, kSlots);
     if (!ctx) Fatal("ColumnarBatchEncoder", fpvhip_last_error(nullptr));
-    worker = std::thread(&Impl::Work, this);  // last: everything it touches exists
+    for (auto& w : workers) w = std::thread(&Impl::Work, this);  // last: everything they touch exists
   }
 
   ~Impl() {
-    if (worker.joinable()) worker.join();
+    for (auto& w : workers)
+      if (w.joinable()) w.join();
     if (ctx) ReleaseEncoderCtx(ctx);
   }
 
   void SubmitOpenLocked() {  // m held, open_slot has frames
     if (fpvhip_predict_submit(ctx, (uint32_t)open_slot, (uint32_t)open_ts.size(), 1))
       Fatal("fpvhip_predict_submit", fpvhip_last_error(ctx));
-    submitted.push_back(Pending{(uint32_t)open_slot, std::move(open_ts)});
+    submitted.push_back(Pending{(uint32_t)open_slot, std::move(open_ts), next_seq++});
     open_ts.clear();
     open_slot = -1;
     cv.notify_all();
@@ -284,21 +289,32 @@ struct ColumnarBatchEncoder::Impl {
                                      sp[k].data(), sp[k].size()))
           Fatal("ColumnarBatchEncoder", "batch column overflow");
       {
-        std::lock_guard<std::mutex> l(m);
+        std::unique_lock<std::mutex> l(m);
         slot_busy[p.slot] = 0;  // the pinned planes have been consumed
+        cv.notify_all();
+        // two workers overlap the Brotli of one batch with the column copies and the
+        // processor call of the one before; batches still leave in submission order
+        cv.wait(l, [&] { return next_emit == p.seq; });
         latest_stored = batch->LatestTimestamp();
       }
+      processor(batch);  // one batch at a time, in order
+      {
+        std::lock_guard<std::mutex> l(m);
+        next_emit++;
+      }
       cv.notify_all();
-      processor(batch);  // on this thread, one batch at a time, in order
     }
-    // cb/columnar_batch_encoder.cc:82-91: nothing left to flush -> a null batch
-    bool announce_empty;
+    // cb/columnar_batch_encoder.cc:82-91: nothing left to flush -> a null batch.  The
+    // last worker to leave closes the stream.
+    bool last_out, announce_empty;
     int64_t last;
     {
       std::lock_guard<std::mutex> l(m);
-      announce_empty = flushed_partial == false;
+      last_out = --workers_left == 0;
+      announce_empty = !flushed_partial;
       last = latest_stored;
     }
+    if (!last_out) return;
     if (announce_empty) processor(nullptr);
     closing_promise.set_value(last);
   }
@@ -327,8 +343,8 @@ std::future<void*> ColumnarBatchEncoder::PushFrame(uint64_t timestamp, uint16_t*
     s.schema = schema;
   }
   if (s.open_slot < 0) {
-    s.cv.wait(l, [&] { return !s.slot_busy[0] || !s.slot_busy[1]; });
-    s.open_slot = s.slot_busy[0] ? 1 : 0;
+    s.cv.wait(l, [&] { return !s.slot_busy[0] || !s.slot_busy[1] || !s.slot_busy[2]; });
+    s.open_slot = !s.slot_busy[0] ? 0 : !s.slot_busy[1] ? 1 : 2;
     s.slot_busy[s.open_slot] = 1;
   }
   const int slot = s.open_slot;

@@ -219,7 +219,7 @@ __global__ __launch_bounds__(kThreads) void k_unextract(uint16_t* __restrict__ p
 // The speculation only ever changes speed: every frame's output is produced
 // under its TRUE flags.
 
-constexpr int kMaxIter = 5;        // 16-pixel segments per thread and tile held in registers
+constexpr int kMaxIter = 8;        // passes of 256 threads x 16 pixels over a redo tile (bounds its LDS: xsize <= 8192)
 constexpr int kHistFused = 3;      // partial histograms per tile: d, a, b
 constexpr int kListGrid = 1024;    // workgroups of the list-driven kernels
 

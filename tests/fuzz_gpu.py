@@ -4,7 +4,7 @@ CPU oracle (test infrastructure, like everything under tests/): random geometrie
 predict and inverse, plus inverse on arbitrary planes with forced flags.
 
   python tests/fuzz_gpu.py [seconds] [seed]      -> one summary line, exit 1 on a mismatch
-  FUZZ_BIG=1: a quarter of the cases use wide / tall frames (up to 5120 x 316)
+  FUZZ_BIG=1: a quarter of the cases use wide / tall frames (up to 8192 x 316)
 """
 import importlib
 import os
@@ -61,7 +61,7 @@ while time.time() - t0 < budget:
     xs = int(rng.choice([rng.integers(1, 40) * 4, rng.integers(64, 520) * 4, 256, 1280, 1536]))
     ys = int(rng.integers(1, 24)) * 4
     if big:
-        xs = int(rng.choice([1920, 2560, 4096, rng.integers(400, 1281) * 4]))   # encode side: xsize <= 5120
+        xs = int(rng.choice([1920, 2560, 4096, rng.integers(400, 2049) * 4]))   # encode side: xsize <= 8192
         ys = int(rng.integers(8, 80)) * 4
     be = bool(rng.integers(0, 2))
     shift = int(rng.choice([0, 0, 4, 8, 2, 6])) if be else int(rng.choice([0, 0, 4, 8, 2, 6, 12]))

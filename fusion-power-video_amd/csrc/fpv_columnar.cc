@@ -40,23 +40,6 @@ using namespace fpvc::internal;
 namespace {
 size_t RoundUp64(size_t v) { return (v + 63) & ~(size_t)63; }
 
-// Runs fn(i) for i in [0, n) on up to `threads` threads (the caller's included).
-template <typename F>
-void ParallelFor(size_t n, size_t threads, F fn) {
-  std::atomic<size_t> next(0);
-  auto work = [&] {
-    for (;;) {
-      const size_t i = next.fetch_add(1);
-      if (i >= n) return;
-      fn(i);
-    }
-  };
-  std::vector<std::thread> pool;
-  for (size_t t = 1; t < std::min(threads, n); t++) pool.emplace_back(work);
-  work();
-  for (auto& t : pool) t.join();
-}
-
 size_t WorkerThreads() {
   return EnvSize("FPV_COLUMNAR_THREADS", std::max(1u, std::min(16u, std::thread::hardware_concurrency())));
 }

@@ -233,19 +233,9 @@ bool InverseEngine::RunBatches(size_t n, const Unpacker& unpack, const Sink& sin
       finish(prev);
       return FPV_FAILURE(fpvhip_last_error(ctx_));
     }
-    std::atomic<size_t> next(0);
-    auto work = [&]() {
-      for (;;) {
-        size_t i = next.fetch_add(1);
-        if (i >= count) return;
-        good[i] = unpack(first + i, (uint32_t)s, (uint32_t)i, &flags[i]);
-      }
-    };
-    const size_t nt = std::min(threads, count);
-    std::vector<std::thread> pool;
-    for (size_t t = 1; t < nt; t++) pool.emplace_back(work);
-    work();
-    for (auto& t : pool) t.join();
+    ParallelFor(count, threads, [&](size_t i) {
+      good[i] = unpack(first + i, (uint32_t)s, (uint32_t)i, &flags[i]);
+    });
     size_t usable = 0;  // images in front of the first failure
     while (usable < count && good[usable]) usable++;
     if (usable > 0 &&

@@ -21,6 +21,8 @@
 #include <chrono>
 #include <condition_variable>
 #include <deque>
+#include <functional>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -114,6 +116,86 @@ bool BrotliInto(const uint8_t* in, size_t size, size_t* pos, uint8_t* dst,
   *pos = size - avail_in;
   *got = cap - avail_out;
   return r == BROTLI_DECODER_RESULT_SUCCESS;
+}
+
+// ------------------------------------------------------------- thread pool --
+
+namespace {
+// A job is a range of indices handed out one at a time; helpers and the caller pull
+// from it until it is exhausted.  The pool's threads are detached and parked on a
+// condition variable; they are never joined (the process simply ends).
+struct PoolJob {
+  const std::function<void(size_t)>* fn;
+  size_t n;
+  std::atomic<size_t> next{0}, done{0};
+  size_t helpers_wanted;  // how many pool threads may still join this job
+};
+struct Pool {
+  std::mutex m;
+  std::condition_variable cv_work, cv_done;
+  std::deque<std::shared_ptr<PoolJob>> jobs;  // jobs that still want helpers
+  size_t threads = 0;
+};
+Pool& ThePool() {
+  static Pool* p = new Pool();  // leaked on purpose: parked threads may outlive static destruction
+  return *p;
+}
+void RunJob(PoolJob& j) {
+  for (;;) {
+    const size_t i = j.next.fetch_add(1);
+    if (i >= j.n) return;
+    (*j.fn)(i);
+    if (j.done.fetch_add(1) + 1 == j.n) {
+      Pool& p = ThePool();
+      std::lock_guard<std::mutex> l(p.m);
+      p.cv_done.notify_all();
+    }
+  }
+}
+void PoolThread() {
+  Pool& p = ThePool();
+  std::unique_lock<std::mutex> l(p.m);
+  for (;;) {
+    p.cv_work.wait(l, [&] { return !p.jobs.empty(); });
+    std::shared_ptr<PoolJob> j = p.jobs.front();
+    if (--j->helpers_wanted == 0) p.jobs.pop_front();
+    l.unlock();
+    RunJob(*j);
+    l.lock();
+  }
+}
+}  // namespace
+
+void ParallelFor(size_t n, size_t threads, const std::function<void(size_t)>& fn) {
+  if (n == 0) return;
+  const size_t helpers = std::min<size_t>(std::min(threads, n), 64) - (threads && n ? 1 : 0);
+  if (helpers == 0 || threads <= 1) {
+    for (size_t i = 0; i < n; i++) fn(i);
+    return;
+  }
+  std::shared_ptr<PoolJob> j = std::make_shared<PoolJob>();
+  j->fn = &fn;
+  j->n = n;
+  j->helpers_wanted = helpers;
+  Pool& p = ThePool();
+  {
+    std::lock_guard<std::mutex> l(p.m);
+    while (p.threads < helpers) {  // grow the pool to what this call can use
+      std::thread(PoolThread).detach();
+      p.threads++;
+    }
+    p.jobs.push_back(j);
+  }
+  p.cv_work.notify_all();
+  RunJob(*j);
+  std::unique_lock<std::mutex> l(p.m);
+  p.cv_done.wait(l, [&] { return j->done.load() == j->n; });
+  // helpers that have not picked the job up yet must not: its fn dies with this frame
+  for (auto it = p.jobs.begin(); it != p.jobs.end(); ++it)
+    if (it->get() == j.get()) {
+      p.jobs.erase(it);
+      break;
+    }
 }
 
 // ----------------------------------------------------------------- devices --

@@ -31,6 +31,12 @@ bool BrotliAppend(const uint8_t* in, size_t n, std::vector<uint8_t>* out);
 bool BrotliInto(const uint8_t* in, size_t size, size_t* pos, uint8_t* dst,
                 size_t cap, size_t* got);
 
+// Runs fn(i) for every i in [0, n) on up to `threads` threads, the caller's included;
+// returns when all are done.  The helpers come from a process-wide pool of parked
+// threads (created on first need, never more than 64), so that per-batch fan-outs --
+// Brotli of the planes of a batch, in both directions -- do not pay for thread creation.
+void ParallelFor(size_t n, size_t threads, const std::function<void(size_t)>& fn);
+
 std::vector<int> DeviceList();
 size_t EnvSize(const char* name, size_t dflt);
 

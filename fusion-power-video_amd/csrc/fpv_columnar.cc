@@ -254,10 +254,12 @@ struct ColumnarBatchEncoder::Impl {
       const size_t n = p.ts.size();
       // Brotli of the 3 planes of every frame, frames in parallel (cc:643-688 per plane)
       std::vector<std::vector<uint8_t>> sh(n), sl(n), sp(n);
-      // one task per plane (low planes first: they are the expensive ones), so that a
-      // batch of few frames still spreads over all threads
+      // One task per plane, so that a batch of few frames still spreads over all threads;
+      // frame-major order, so that low, high and preview planes are in progress at the
+      // same time (sixteen threads all on low planes -- the incompressible, memory-heavy
+      // ones -- measured ~20 % slower in the Encoder).
       ParallelFor(3 * n, threads, [&](size_t t) {
-        const size_t k = t % n, which = t / n;
+        const size_t k = t / 3, which = t % 3;
         if (which == 0) {
           if (!(flags[k] & NO_LOW_BYTES) && !BrotliAppend(low + k * npix, npix, &sl[k])) Fatal("Brotli", "low plane");
         } else if (which == 1) {

@@ -2022,9 +2022,12 @@ static void spec_geom(Geom* g) {
   if ((g->xs & 3) || (g->npix & 3) || g->xs < 256) return;
   uint32_t k4 = std::min(kSpecMaxK4, g->xs / 256);
   if (const char* e = getenv("FPV_SPEC_K4")) k4 = std::max(1u, std::min(k4, (uint32_t)atoi(e)));
-  g->spec_k4 = k4;
   uint32_t r = 1;
   while (r < g->xs + 256 * k4 + 16) r <<= 1;
+  // ring + the three-wave kernel's staging buffers must fit the default 64 KiB of dynamic
+  // LDS (frames wider than ~45 K pixels: the serial-chain kernels take over)
+  if (r + 10 * 256 * k4 > 64 * 1024) return;
+  g->spec_k4 = k4;
   g->spec_ring = r;
 }
 
@@ -2376,7 +2379,7 @@ hipError_t launch_inverse(const Geom& g, const uint8_t* d_high,
       default: return hipErrorInvalidValue;
     }
 #undef FPV_LAUNCH_SPEC
-  } else if (mode != 2 && aligned && g.xs >= kInvC) {
+  } else if (mode != 2 && aligned && g.xs >= kInvC && (g.inv_ring + 4 * kInvC) * 4 <= 160 * 1024 - 64) {
     k_inverse_fast<<<nframes, 64, (g.inv_ring + 4 * kInvC) * 4, s>>>(d_high, d_low, d_dhigh, d_dlow,
                                                                      d_flags, d_frames, g);
   } else if (aligned) {

@@ -112,3 +112,14 @@ def test_decode_frames_raw_fused_unextract(codec, synth, shift, be):
     assert np.array_equal(raw.reshape(-1), src.reshape(-1).view(np.uint8))
     dec = codec.decode_stream(fpv)
     assert np.array_equal(raw[3], codec.unextract(dec[3], xs, ys, shift, be))
+
+
+def test_decoder_accepts_very_wide_frames(codec, oracle):
+    """Decoders take any geometry the container can hold (up to 65536 wide): beyond the
+    LDS budget of the speculative inverse kernels the serial-chain kernels take over."""
+    for xs, ys in ((50000, 2), (65536, 1)):
+        rng = np.random.default_rng(xs)
+        fr = (np.cumsum(rng.integers(0, 9, (2, ys, xs)), axis=2) * 5 + rng.integers(0, 50, (2, ys, xs))).astype(np.uint16)
+        stream = oracle.encode_stream(fr, fr[0], xs, ys, 0, False)
+        assert np.array_equal(codec.decode_stream(stream), fr)
+        assert np.array_equal(codec.decode_stream(stream, batched=True, threads=2), fr)

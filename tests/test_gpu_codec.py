@@ -123,3 +123,16 @@ def test_decoder_accepts_very_wide_frames(codec, oracle):
         stream = oracle.encode_stream(fr, fr[0], xs, ys, 0, False)
         assert np.array_equal(codec.decode_stream(stream), fr)
         assert np.array_equal(codec.decode_stream(stream, batched=True, threads=2), fr)
+
+
+@pytest.mark.parametrize("xs,ys", [(8, 4096), (4, 16384), (8192, 64), (4096, 260), (20, 1000)])
+def test_extreme_aspect_ratios(codec, oracle, xs, ys):
+    """Tall-and-narrow and wide-and-short frames through the whole codec: stream bytes
+    identical to the oracle's, both decoders return the pixels."""
+    rng = np.random.default_rng(xs * 31 + ys)
+    fr = (np.cumsum(rng.integers(0, 12, (3, ys, xs)), axis=1) * 3 + rng.integers(0, 90, (3, ys, xs)) + 500).astype(np.uint16)
+    want = oracle.encode_stream(fr, fr[0], xs, ys, 0, False)
+    got = codec.encode_stream(fr, fr[0], xs, ys, 0, False, threads=3)
+    assert np.array_equal(got, want)
+    assert np.array_equal(codec.decode_stream(got), fr)
+    assert np.array_equal(codec.stream_decode(got, xs, ys, 3, block=0), fr)

@@ -136,3 +136,32 @@ def test_extreme_aspect_ratios(codec, oracle, xs, ys):
     assert np.array_equal(got, want)
     assert np.array_equal(codec.decode_stream(got), fr)
     assert np.array_equal(codec.stream_decode(got, xs, ys, 3, block=0), fr)
+
+
+def test_concurrent_sessions_in_one_process(codec, synth):
+    """Several encoder / decoder sessions at once from different threads (ctypes drops
+    the GIL during the calls): contexts come from the process-wide pool, kernels run on
+    independent streams; every session must produce what it produces alone."""
+    import threading
+    jobs = []
+    for seed, (xs, ys, shift) in enumerate([(320, 200, 4), (256, 256, 0), (320, 200, 4), (1280, 800, 4)]):
+        fr = synth.plasma_frames(12, xs, ys, bits=12 if shift else 16, seed=40 + seed)
+        jobs.append((fr, xs, ys, shift))
+    alone = [codec.encode_stream(fr, fr[0], xs, ys, shift, False, threads=3) for fr, xs, ys, shift in jobs]
+    results = [None] * len(jobs)
+    decoded = [None] * len(jobs)
+
+    def run(i):
+        fr, xs, ys, shift = jobs[i]
+        results[i] = codec.encode_stream(fr, fr[0], xs, ys, shift, False, threads=3)
+        decoded[i] = codec.decode_stream(results[i], batched=True, threads=2)
+
+    for _ in range(2):
+        ts = [threading.Thread(target=run, args=(i,)) for i in range(len(jobs))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        for i, (fr, xs, ys, shift) in enumerate(jobs):
+            assert np.array_equal(results[i], alone[i]), f"session {i} differs when run concurrently"
+            assert np.array_equal(decoded[i], fr << shift)

@@ -16,5 +16,5 @@ def test_threadsanitizer_host_pipeline():
     if "cannot find -ltsan" in r.stderr or "libtsan" in r.stderr and "No such file" in r.stderr:
         pytest.skip("no libtsan in this toolchain")
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    assert r.stdout.count(" ok, ") == 4
+    assert r.stdout.count(" ok, ") == 4 and "concurrent sessions ok" in r.stdout
     assert r.stdout.count("columnar ok") == 5   # the columnar adapter's queues and futures

@@ -27,7 +27,7 @@ HOST_SRC := $(CSRC)/fpv_host.cc $(CSRC)/fpv_decoders.cc $(CSRC)/fpv_frame.cc $(C
 HOST_HDR := include/fusion_power_video.h include/fpv_hip.h include/fpv_c_api.h $(CSRC)/fpv_host_internal.h $(CSRC)/fpv_frame_capi.inc \
             $(wildcard include/columnar_batch/*.h)
 
-all: product tools oracle shim refcli refcb columnar
+all: product tools oracle shim refcli refcb columnar arrow
 
 product: $(LIBDIR)/libfpvhip.so $(LIBDIR)/libfpv_amd.so
 
@@ -112,6 +112,49 @@ $(BINDIR)/ref_cbtest_native_%: build/refsrc_native/columnar_batch_%_test.cc $(LI
 	    -Wl,-rpath,'$$ORIGIN/../../$(LIBDIR)' -Wl,-rpath,$(ROCM_LIB) -o $@
 endif
 
+# Arrow record-batch encoder: needs an Arrow C++ installation.  The image
+# has none of its own, but pyarrow ships the headers and libarrow; built only when found.
+PYARROW := $(shell python3 -c "import pyarrow, sys; sys.stdout.write(pyarrow.get_library_dirs()[0])" 2>/dev/null)
+ARROW_SO := $(firstword $(wildcard $(PYARROW)/libarrow.so.[0-9]*))
+ifneq ($(ARROW_SO),)
+ARROWFLAGS := -std=c++20 -O2 -fPIC -Wall -Iinclude -I$(CSRC) -I$(PYARROW)/include
+arrow: $(LIBDIR)/libfpv_arrow.so $(BINDIR)/arrow_driver tests/shim/arrow_driver_cpushim
+$(LIBDIR)/libfpv_arrow.so: $(CSRC)/fpv_arrow.cc include/fpv_arrow/arrow_encoder.h $(LIBDIR)/libfpv_amd.so
+	$(CXX) $(ARROWFLAGS) -shared $< -L$(LIBDIR) -lfpv_amd $(ARROW_SO) -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,$(PYARROW) -o $@
+$(BINDIR)/arrow_driver: tests/arrow_driver.cc $(LIBDIR)/libfpv_arrow.so
+	@mkdir -p $(BINDIR)
+	$(CXX) $(ARROWFLAGS) $< -L$(LIBDIR) -lfpv_arrow -lfpv_amd -lfpvhip $(ARROW_SO) -lpthread \
+	    -Wl,-rpath,'$$ORIGIN/../../$(LIBDIR)' -Wl,-rpath,$(ROCM_LIB) -Wl,-rpath,$(PYARROW) -o $@
+# CPU variant: the adapter's source together with the test shim build of the codec
+tests/shim/arrow_driver_cpushim: tests/arrow_driver.cc $(CSRC)/fpv_arrow.cc tests/shim/libfpv_amd_cpushim.so
+	$(CXX) $(ARROWFLAGS) tests/arrow_driver.cc $(CSRC)/fpv_arrow.cc tests/shim/libfpv_amd_cpushim.so $(ARROW_SO) -lpthread \
+	    -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,$(PYARROW) -o $@
+ifneq ($(wildcard $(REF)/arrow/arrow_encoder_test.cc),)
+# upstream's Arrow test compiled UNCHANGED against OUR header + library, and upstream's own
+# adapter compiled unchanged over our Frame API
+arrow: $(BINDIR)/ref_arrowtest_native $(BINDIR)/ref_arrow_encoder_test
+build/refsrc_native/arrow_encoder_test.cc: $(REF)/arrow/arrow_encoder_test.cc
+	@mkdir -p build/refsrc_native
+	ln -sf $< $@
+$(BINDIR)/ref_arrowtest_native: build/refsrc_native/arrow_encoder_test.cc $(LIBDIR)/libfpv_arrow.so
+	@mkdir -p $(BINDIR)
+	$(CXX) -std=c++20 -O2 -w -Iinclude/fpv_arrow -I$(PYARROW)/include $< -L$(LIBDIR) -lfpv_arrow -lfpv_amd -lfpvhip $(ARROW_SO) -lpthread \
+	    -Wl,-rpath,'$$ORIGIN/../../$(LIBDIR)' -Wl,-rpath,$(ROCM_LIB) -Wl,-rpath,$(PYARROW) -o $@
+build/refsrc/arrow/.linked: $(wildcard $(REF)/arrow/*) build/refsrc/fusion_power_video.h
+	@mkdir -p build/refsrc/arrow
+	for f in $(REF)/arrow/*.cc $(REF)/arrow/*.h; do ln -sf $$f build/refsrc/arrow/; done
+	touch $@
+$(BINDIR)/ref_arrow_encoder_test: build/refsrc/arrow/.linked $(LIBDIR)/libfpv_amd.so
+	@mkdir -p $(BINDIR)
+	$(CXX) -std=c++20 -O2 -w -I$(PYARROW)/include build/refsrc/arrow/arrow_encoder.cc build/refsrc/arrow/arrow_encoder_test.cc \
+	    -L$(LIBDIR) -lfpv_amd -lfpvhip $(ARROW_SO) -lpthread \
+	    -Wl,-rpath,'$$ORIGIN/../../$(LIBDIR)' -Wl,-rpath,$(ROCM_LIB) -Wl,-rpath,$(PYARROW) -o $@
+endif
+else
+arrow:
+	@echo "arrow: no Arrow C++ found (pyarrow not importable), skipped"
+endif
+
 oracle:
 	$(MAKE) -C oracle REF=$(REF)
 
@@ -149,7 +192,7 @@ build/tsan/driver: tests/shim/tsan_driver.cc tests/shim/fpvhip_oracle_shim.c ora
 	$(CXX) $(CXXFLAGS) -O1 -g -fsanitize=thread tests/shim/tsan_driver.cc $(HOST_SRC) build/tsan/shim.o build/tsan/oracle.o $(BROTLI) -o $@
 
 clean:
-	rm -rf $(LIBDIR) build tests/shim/*.so tests/shim/*.o tests/shim/columnar_driver_cpushim
+	rm -rf $(LIBDIR) build tests/shim/*.so tests/shim/*.o tests/shim/columnar_driver_cpushim tests/shim/arrow_driver_cpushim
 	$(MAKE) -C oracle clean
 
-.PHONY: all product tools oracle shim refcli refcb columnar asan tsan clean
+.PHONY: all product tools oracle shim refcli refcb columnar arrow asan tsan clean

@@ -1,0 +1,129 @@
+// TEST DRIVER for the native ArrowEncoder (include/fpv_arrow/arrow_encoder.h): frames ->
+// Arrow record batches; checks the schema and its metadata, then rebuilds columnar
+// batches from the record batches' arrays (delta frame from the schema metadata) and
+// decodes them with the ColumnarBatchDecoder: every pixel must come back.
+// Prints "arrow ok ..." and returns 0, or a message and non-zero.
+#include <arrow/api.h>
+#include <arrow/util/key_value_metadata.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../include/columnar_batch/columnar_batch_decoder.h"
+#include "../include/fpv_arrow/arrow_encoder.h"
+
+using namespace fpvc;
+using namespace fpvc::columnarbatch;
+
+#define CHECK(c, ...)                                    \
+  do {                                                   \
+    if (!(c)) {                                          \
+      fprintf(stderr, "FAIL %s:%d: ", __FILE__, __LINE__); \
+      fprintf(stderr, __VA_ARGS__);                      \
+      fputc('\n', stderr);                               \
+      return 1;                                          \
+    }                                                    \
+  } while (0)
+
+static int RunCase(size_t xs, size_t ys, size_t n, int shift, int per_batch) {
+  const size_t npix = xs * ys;
+  std::vector<std::vector<uint16_t>> frames(n, std::vector<uint16_t>(npix));
+  uint32_t s = 4242 + (uint32_t)xs;
+  const uint32_t vmask = (1u << (16 - shift)) - 1;
+  for (size_t k = 0; k < n; k++)
+    for (size_t i = 0; i < npix; i++) {
+      s = s * 1664525u + 1013904223u;
+      frames[k][i] = (uint16_t)(((i % xs) * 11 + (i / xs) * 23 + k * 257 + ((s >> 28) & 3)) & vmask);
+    }
+  std::vector<std::shared_ptr<arrow::RecordBatch>> batches;
+  size_t nulls = 0;
+  int64_t end;
+  {
+    ArrowEncoder enc(xs, ys, shift, false, [&](std::shared_ptr<arrow::RecordBatch> b) {
+      if (b) batches.push_back(b); else nulls++;
+    }, per_batch);
+    std::vector<uint16_t> buf(npix);
+    for (size_t k = 0; k < n; k++) {
+      memcpy(buf.data(), frames[k].data(), npix * 2);
+      std::future<void*> f = enc.PushFrame(5000 + k, buf.data(), &buf);
+      CHECK(f.valid() && f.get() == &buf, "PushFrame future");
+      memset(buf.data(), 0x77, npix * 2);
+    }
+    end = enc.Close().get();
+  }
+  CHECK(end == (int64_t)(5000 + n - 1), "closing timestamp %lld", (long long)end);
+  CHECK(batches.size() == (n + per_batch - 1) / per_batch, "%zu record batches", batches.size());
+  CHECK(nulls == (n % per_batch == 0 ? 1u : 0u), "%zu null batches", nulls);
+
+  // schema and metadata (arrow/arrow_encoder.cc:80-98)
+  std::shared_ptr<arrow::Schema> sc = batches[0]->schema();
+  const char* names[6] = {"timestamp", "deltaPredicted", "cgPredicted", "preview", "highBytePlane", "lowBytePlane"};
+  CHECK(sc->num_fields() == 6, "field count");
+  for (int i = 0; i < 6; i++) CHECK(sc->field(i)->name() == names[i] && !sc->field(i)->nullable(), "field %d", i);
+  CHECK(sc->field(0)->type()->Equals(arrow::timestamp(arrow::TimeUnit::NANO)), "timestamp type");
+  CHECK(sc->field(1)->type()->id() == arrow::Type::BOOL && sc->field(4)->type()->id() == arrow::Type::BINARY, "types");
+  auto md = sc->metadata();
+  CHECK(md && md->Get("xsize").ValueOr("") == std::to_string(xs) && md->Get("ysize").ValueOr("") == std::to_string(ys) &&
+            md->Get("shiftedLeft").ValueOr("") == std::to_string(shift), "geometry metadata");
+  const std::string dh = md->Get("deltaFrameHighPlane").ValueOr(""), dl = md->Get("deltaFrameLowPlane").ValueOr("");
+  const bool dcg = md->Get("deltaFrameCGPredicted").ValueOr("") == "true";
+  CHECK(!dh.empty(), "delta frame stream missing");
+
+  // the delta frame back from the metadata, then a columnar schema around it
+  Frame delta(xs, ys, (uint8_t)((dcg ? FrameFlags::USE_CG : 0) | (dl.empty() ? FrameFlags::NO_LOW_BYTES : 0)),
+              (uint8_t)(FrameState::COMPRESSED | FrameState::CG_PREDICTED | FrameState::DELTA_PREDICTED),
+              std::vector<uint8_t>(dh.begin(), dh.end()), std::vector<uint8_t>(dl.begin(), dl.end()),
+              std::vector<uint8_t>());
+  delta.Uncompress();
+  for (size_t i = 0; i < npix; i++) {
+    const uint16_t want = (uint16_t)(frames[0][i] << shift);
+    const uint16_t got = (uint16_t)((delta.high()[i] << 8) | (i < delta.low().size() ? delta.low()[i] : 0));
+    CHECK(got == want, "delta frame from the metadata differs at pixel %zu", i);
+  }
+  SchemaPtr schema = std::make_shared<BatchSchema>(xs, ys, (size_t)shift, delta);
+
+  size_t seen = 0;
+  int bad = 0;
+  ColumnarBatchDecoder dec(Image::FULL, true, [&](Image img) {
+    const size_t k = img.timestamp() - 5000;
+    if (k != seen++ || k >= n) { bad++; return; }
+    for (size_t i = 0; i < npix; i++)
+      if (img.data16()[i] != frames[k][i]) { bad++; return; }
+  });
+  for (auto& rb : batches) {
+    const int64_t rows = rb->num_rows();
+    auto ts = std::static_pointer_cast<arrow::TimestampArray>(rb->column(0));
+    auto fd = std::static_pointer_cast<arrow::BooleanArray>(rb->column(1));
+    auto fc = std::static_pointer_cast<arrow::BooleanArray>(rb->column(2));
+    auto pv = std::static_pointer_cast<arrow::BinaryArray>(rb->column(3));
+    auto hi = std::static_pointer_cast<arrow::BinaryArray>(rb->column(4));
+    auto lo = std::static_pointer_cast<arrow::BinaryArray>(rb->column(5));
+    BatchPtr b = std::make_shared<Batch>((size_t)rows, schema);
+    for (int64_t i = 0; i < rows; i++) {
+      int32_t hn, ln, pn;
+      const uint8_t *h = hi->GetValue(i, &hn), *l = lo->GetValue(i, &ln), *p = pv->GetValue(i, &pn);
+      const uint8_t flags = (uint8_t)((fd->Value(i) ? FrameFlags::USE_DELTA : 0) | (fc->Value(i) ? FrameFlags::USE_CG : 0) |
+                                      (ln == 0 ? FrameFlags::NO_LOW_BYTES : 0));
+      CHECK(b->AppendCompressed(ts->Value(i), flags, h, (size_t)hn, l, (size_t)ln, p, (size_t)pn), "AppendCompressed");
+    }
+    std::future<BatchPtr> f = dec.PushBatch(b);
+    CHECK(f.valid(), "PushBatch");
+    f.get();
+  }
+  CHECK(dec.Close().get() == end, "decoder closing timestamp");
+  CHECK(seen == n && bad == 0, "%zu of %zu images, %d bad", seen, n, bad);
+  printf("arrow ok: %zux%zu, %zu frames, shift %d, %d per batch, %zu record batches\n", xs, ys, n, shift, per_batch,
+         batches.size());
+  return 0;
+}
+
+int main() {
+  if (RunCase(64, 48, 11, 4, 4)) return 1;
+  if (RunCase(320, 200, 6, 0, 3)) return 1;
+  if (RunCase(100, 100, 3, 0, 2)) return 1;
+  return 0;
+}

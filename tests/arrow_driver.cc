@@ -4,6 +4,8 @@
 // decodes them with the ColumnarBatchDecoder: every pixel must come back.
 // Prints "arrow ok ..." and returns 0, or a message and non-zero.
 #include <arrow/api.h>
+#include <arrow/io/file.h>
+#include <arrow/ipc/writer.h>
 #include <arrow/util/key_value_metadata.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -116,6 +118,17 @@ static int RunCase(size_t xs, size_t ys, size_t n, int shift, int per_batch) {
   }
   CHECK(dec.Close().get() == end, "decoder closing timestamp");
   CHECK(seen == n && bad == 0, "%zu of %zu images, %d bad", seen, n, bad);
+  // FPV_ARROW_IPC_OUT=<path>: the record batches of this case as an Arrow IPC file, for a
+  // consumer that is not this code base (tests/test_arrow.py reads it with pyarrow)
+  if (const char* path = getenv("FPV_ARROW_IPC_OUT")) {
+    auto sink = arrow::io::FileOutputStream::Open(path);
+    CHECK(sink.ok(), "cannot open %s", path);
+    auto writer = arrow::ipc::MakeFileWriter(*sink, sc);
+    CHECK(writer.ok(), "MakeFileWriter");
+    for (auto& rb : batches) CHECK((*writer)->WriteRecordBatch(*rb).ok(), "WriteRecordBatch");
+    CHECK((*writer)->Close().ok() && (*sink)->Close().ok(), "closing the IPC file");
+    unsetenv("FPV_ARROW_IPC_OUT");  // first case only
+  }
   printf("arrow ok: %zux%zu, %zu frames, shift %d, %d per batch, %zu record batches\n", xs, ys, n, shift, per_batch,
          batches.size());
   return 0;

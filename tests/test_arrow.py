@@ -27,6 +27,33 @@ def test_arrow_driver_over_cpu_shim():
     assert r.stdout.count("arrow ok") == 3
 
 
+def test_record_batches_are_readable_by_pyarrow(tmp_path):
+    """Interoperability: the record batches written as an Arrow IPC file are read back by
+    pyarrow (a consumer that shares no code with this repository): schema, metadata, rows."""
+    pa = pytest.importorskip("pyarrow")
+    path = os.path.join(ROOT, "tests", "shim", "arrow_driver_cpushim")
+    if not os.path.exists(path):
+        pytest.skip("arrow driver not built")
+    out = str(tmp_path / "frames.arrow")
+    r = subprocess.run([path], capture_output=True, text=True, errors="replace", timeout=300,
+                       env=dict(os.environ, FPV_ARROW_IPC_OUT=out))
+    assert r.returncode == 0, r.stdout + r.stderr
+    with pa.ipc.open_file(out) as f:
+        table = f.read_all()
+        assert f.num_record_batches == 3                       # 11 frames, 4 per batch
+    assert table.num_rows == 11
+    assert table.schema.names == ["timestamp", "deltaPredicted", "cgPredicted", "preview", "highBytePlane", "lowBytePlane"]
+    assert table.schema.field("timestamp").type == pa.timestamp("ns") and not table.schema.field("timestamp").nullable
+    assert table.schema.field("highBytePlane").type == pa.binary()
+    md = table.schema.metadata
+    assert md[b"xsize"] == b"64" and md[b"ysize"] == b"48" and md[b"shiftedLeft"] == b"4"
+    assert len(md[b"deltaFrameHighPlane"]) > 0 and md[b"deltaFrameCGPredicted"] in (b"true", b"false")
+    assert table.column("timestamp").cast(pa.int64()).to_pylist() == list(range(5000, 5011))
+    assert all(len(v) > 0 for v in table.column("highBytePlane").to_pylist())
+    assert all(len(v) > 0 for v in table.column("preview").to_pylist())
+    assert table.column("deltaPredicted").to_pylist()[1] is True  # frames after the first differ from the delta frame
+
+
 @pytest.mark.gpu
 def test_arrow_driver_on_gpu():
     r = _run(os.path.join(BIN, "arrow_driver"))

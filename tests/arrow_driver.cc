@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <memory>
 #include <string>
 #include <vector>
@@ -134,7 +135,38 @@ static int RunCase(size_t xs, size_t ys, size_t n, int shift, int per_batch) {
   return 0;
 }
 
+// FPV_ARROW_BENCH=1: throughput at the BASELINE frame size (1280x800 12-bit, shift 4).
+static void Bench() {
+  const size_t xs = 1280, ys = 800, npix = xs * ys, distinct = 16, n = 512;
+  std::vector<std::vector<uint16_t>> src(distinct, std::vector<uint16_t>(npix));
+  uint32_t s = 99;
+  for (size_t k = 0; k < distinct; k++)
+    for (size_t i = 0; i < npix; i++) {
+      s = s * 1664525u + 1013904223u;
+      src[k][i] = (uint16_t)(((i % xs) * 3 + (i / xs) * 2 + k * 37 + ((s >> 29) & 7)) & 0xfff);
+    }
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  size_t rows = 0, bytes = 0;
+  const double t0 = now();
+  {
+    ArrowEncoder enc(xs, ys, 4, false, [&](std::shared_ptr<arrow::RecordBatch> b) {
+      if (!b) return;
+      rows += (size_t)b->num_rows();
+      for (int c = 3; c < 6; c++) bytes += (size_t)std::static_pointer_cast<arrow::BinaryArray>(b->column(c))->total_values_length();
+    }, 16);
+    for (size_t k = 0; k < n; k++) enc.PushFrame(k, src[k % distinct].data(), nullptr).get();
+    enc.Close().get();
+  }
+  const double dt = now() - t0;
+  printf("arrow bench: %zu frames %zux%zu, 16 per batch: %.1f fps into record batches (%zu rows, %.3f bpp)\n", n, xs, ys,
+         n / dt, rows, bytes * 8.0 / (n * npix));
+}
+
 int main() {
+  if (getenv("FPV_ARROW_BENCH")) {
+    Bench();
+    return 0;
+  }
   if (RunCase(64, 48, 11, 4, 4)) return 1;
   if (RunCase(320, 200, 6, 0, 3)) return 1;
   if (RunCase(100, 100, 3, 0, 2)) return 1;

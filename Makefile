@@ -119,7 +119,7 @@ ARROW_SO := $(firstword $(wildcard $(PYARROW)/libarrow.so.[0-9]*))
 ifneq ($(ARROW_SO),)
 ARROWFLAGS := -std=c++20 -O2 -fPIC -Wall -Iinclude -I$(CSRC) -I$(PYARROW)/include
 arrow: $(LIBDIR)/libfpv_arrow.so $(BINDIR)/arrow_driver tests/shim/arrow_driver_cpushim
-$(LIBDIR)/libfpv_arrow.so: $(CSRC)/fpv_arrow.cc include/fpv_arrow/arrow_encoder.h $(LIBDIR)/libfpv_amd.so
+$(LIBDIR)/libfpv_arrow.so: $(CSRC)/fpv_arrow.cc $(wildcard include/fpv_arrow/*.h) $(LIBDIR)/libfpv_amd.so
 	$(CXX) $(ARROWFLAGS) -shared $< -L$(LIBDIR) -lfpv_amd $(ARROW_SO) -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,$(PYARROW) -o $@
 $(BINDIR)/arrow_driver: tests/arrow_driver.cc $(LIBDIR)/libfpv_arrow.so
 	@mkdir -p $(BINDIR)

@@ -10,7 +10,9 @@
 #include <mutex>
 #include <string>
 
+#include "../../include/columnar_batch/columnar_batch_decoder.h"
 #include "../../include/columnar_batch/columnar_batch_encoder.h"
+#include "../../include/fpv_arrow/arrow_decoder.h"
 #include "../../include/fpv_arrow/arrow_encoder.h"
 
 namespace fpvc {
@@ -115,5 +117,85 @@ std::future<void*> ArrowEncoder::PushFrame(uint64_t timestamp, uint16_t* frame, 
 }
 
 std::shared_future<int64_t> ArrowEncoder::Close() { return impl_->columns->Close(); }
+
+// ============================================================ ArrowDecoder ==
+
+struct ArrowDecoder::Impl {
+  columnarbatch::ColumnarBatchDecoder columns;
+  columnarbatch::SchemaPtr schema;          // built from the first batch's metadata
+  std::string dh, dl;                       // the delta frame streams it was built from
+  size_t xs = 0, ys = 0, shift = 0;
+
+  Impl(columnarbatch::Image::Type t, bool u, columnarbatch::ImageProcessor p) : columns(t, u, std::move(p)) {}
+
+  static bool Fail(const char* what) {
+    fprintf(stderr, "fpv-mi355x: ArrowDecoder: %s\n", what);
+    return false;
+  }
+
+  bool Prepare(const arrow::Schema& sc) {
+    static const char* kNames[6] = {"timestamp", "deltaPredicted", "cgPredicted", "preview", "highBytePlane", "lowBytePlane"};
+    if (sc.num_fields() != 6) return Fail("not an ArrowEncoder schema (field count)");
+    for (int i = 0; i < 6; i++)
+      if (sc.field(i)->name() != kNames[i]) return Fail("not an ArrowEncoder schema (field names)");
+    if (sc.field(0)->type()->id() != arrow::Type::TIMESTAMP || sc.field(1)->type()->id() != arrow::Type::BOOL ||
+        sc.field(2)->type()->id() != arrow::Type::BOOL || sc.field(3)->type()->id() != arrow::Type::BINARY ||
+        sc.field(4)->type()->id() != arrow::Type::BINARY || sc.field(5)->type()->id() != arrow::Type::BINARY)
+      return Fail("not an ArrowEncoder schema (field types)");
+    auto md = sc.metadata();
+    if (!md) return Fail("schema metadata missing");
+    const std::string h = md->Get("deltaFrameHighPlane").ValueOr(""), l = md->Get("deltaFrameLowPlane").ValueOr("");
+    const size_t x = strtoul(md->Get("xsize").ValueOr("0").c_str(), nullptr, 10);
+    const size_t y = strtoul(md->Get("ysize").ValueOr("0").c_str(), nullptr, 10);
+    const size_t sh = strtoul(md->Get("shiftedLeft").ValueOr("0").c_str(), nullptr, 10);
+    if (schema) {
+      if (x != xs || y != ys || sh != shift || h != dh || l != dl) return Fail("record batch of another stream");
+      return true;
+    }
+    if (!x || !y || sh > 15 || h.empty()) return Fail("bad geometry / delta frame in the schema metadata");
+    const bool cg = md->Get("deltaFrameCGPredicted").ValueOr("") == "true";
+    // the delta frame as ArrowEncoder stored it: Frame::Compress()ed without a delta frame
+    Frame delta(x, y, (uint8_t)((cg ? FrameFlags::USE_CG : 0) | (l.empty() ? FrameFlags::NO_LOW_BYTES : 0)),
+                (uint8_t)(FrameState::COMPRESSED | FrameState::CG_PREDICTED | FrameState::DELTA_PREDICTED),
+                std::vector<uint8_t>(h.begin(), h.end()), std::vector<uint8_t>(l.begin(), l.end()), std::vector<uint8_t>());
+    delta.Uncompress();
+    schema = std::make_shared<columnarbatch::BatchSchema>(x, y, sh, delta);
+    xs = x; ys = y; shift = sh; dh = h; dl = l;
+    return true;
+  }
+};
+
+ArrowDecoder::ArrowDecoder(columnarbatch::Image::Type type, bool unshift, columnarbatch::ImageProcessor image_processor)
+    : impl_(new Impl(type, unshift, std::move(image_processor))) {}
+
+ArrowDecoder::~ArrowDecoder() { Close(); }
+
+bool ArrowDecoder::PushRecordBatch(const std::shared_ptr<arrow::RecordBatch>& rb) {
+  if (!rb) return Impl::Fail("null record batch");
+  if (!impl_->Prepare(*rb->schema())) return false;
+  const int64_t rows = rb->num_rows();
+  if (rows == 0) return true;
+  auto ts = std::static_pointer_cast<arrow::TimestampArray>(rb->column(0));
+  auto fd = std::static_pointer_cast<arrow::BooleanArray>(rb->column(1));
+  auto fc = std::static_pointer_cast<arrow::BooleanArray>(rb->column(2));
+  auto pv = std::static_pointer_cast<arrow::BinaryArray>(rb->column(3));
+  auto hi = std::static_pointer_cast<arrow::BinaryArray>(rb->column(4));
+  auto lo = std::static_pointer_cast<arrow::BinaryArray>(rb->column(5));
+  columnarbatch::BatchPtr b = std::make_shared<columnarbatch::Batch>((size_t)rows, impl_->schema);
+  for (int64_t i = 0; i < rows; i++) {
+    int32_t hn, ln, pn;
+    const uint8_t *h = hi->GetValue(i, &hn), *l = lo->GetValue(i, &ln), *p = pv->GetValue(i, &pn);
+    const uint8_t flags = (uint8_t)((fd->Value(i) ? FrameFlags::USE_DELTA : 0) | (fc->Value(i) ? FrameFlags::USE_CG : 0) |
+                                    (ln == 0 ? FrameFlags::NO_LOW_BYTES : 0));  // an empty low stream = no low plane
+    if (!b->AppendCompressed(ts->Value(i), flags, h, (size_t)hn, l, (size_t)ln, p, (size_t)pn))
+      return Impl::Fail("a row does not fit the geometry of the schema");
+  }
+  std::future<columnarbatch::BatchPtr> done = impl_->columns.PushBatch(b);
+  if (!done.valid()) return Impl::Fail("decoder already closed");
+  done.get();
+  return true;
+}
+
+std::shared_future<int64_t> ArrowDecoder::Close() { return impl_->columns.Close(); }
 
 }  // namespace fpvc

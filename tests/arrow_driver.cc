@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../include/columnar_batch/columnar_batch_decoder.h"
+#include "../include/fpv_arrow/arrow_decoder.h"
 #include "../include/fpv_arrow/arrow_encoder.h"
 
 using namespace fpvc;
@@ -87,37 +88,23 @@ static int RunCase(size_t xs, size_t ys, size_t n, int shift, int per_batch) {
     const uint16_t got = (uint16_t)((delta.high()[i] << 8) | (i < delta.low().size() ? delta.low()[i] : 0));
     CHECK(got == want, "delta frame from the metadata differs at pixel %zu", i);
   }
-  SchemaPtr schema = std::make_shared<BatchSchema>(xs, ys, (size_t)shift, delta);
-
+  // all the way back through the library's own ArrowDecoder (an extension): every pixel
   size_t seen = 0;
   int bad = 0;
-  ColumnarBatchDecoder dec(Image::FULL, true, [&](Image img) {
-    const size_t k = img.timestamp() - 5000;
-    if (k != seen++ || k >= n) { bad++; return; }
-    for (size_t i = 0; i < npix; i++)
-      if (img.data16()[i] != frames[k][i]) { bad++; return; }
-  });
-  for (auto& rb : batches) {
-    const int64_t rows = rb->num_rows();
-    auto ts = std::static_pointer_cast<arrow::TimestampArray>(rb->column(0));
-    auto fd = std::static_pointer_cast<arrow::BooleanArray>(rb->column(1));
-    auto fc = std::static_pointer_cast<arrow::BooleanArray>(rb->column(2));
-    auto pv = std::static_pointer_cast<arrow::BinaryArray>(rb->column(3));
-    auto hi = std::static_pointer_cast<arrow::BinaryArray>(rb->column(4));
-    auto lo = std::static_pointer_cast<arrow::BinaryArray>(rb->column(5));
-    BatchPtr b = std::make_shared<Batch>((size_t)rows, schema);
-    for (int64_t i = 0; i < rows; i++) {
-      int32_t hn, ln, pn;
-      const uint8_t *h = hi->GetValue(i, &hn), *l = lo->GetValue(i, &ln), *p = pv->GetValue(i, &pn);
-      const uint8_t flags = (uint8_t)((fd->Value(i) ? FrameFlags::USE_DELTA : 0) | (fc->Value(i) ? FrameFlags::USE_CG : 0) |
-                                      (ln == 0 ? FrameFlags::NO_LOW_BYTES : 0));
-      CHECK(b->AppendCompressed(ts->Value(i), flags, h, (size_t)hn, l, (size_t)ln, p, (size_t)pn), "AppendCompressed");
-    }
-    std::future<BatchPtr> f = dec.PushBatch(b);
-    CHECK(f.valid(), "PushBatch");
-    f.get();
+  {
+    ArrowDecoder dec(Image::FULL, true, [&](Image img) {
+      const size_t k = img.timestamp() - 5000;
+      if (k != seen++ || k >= n) { bad++; return; }
+      for (size_t i = 0; i < npix; i++)
+        if (img.data16()[i] != frames[k][i]) { bad++; return; }
+    });
+    for (auto& rb : batches) CHECK(dec.PushRecordBatch(rb), "PushRecordBatch");
+    CHECK(dec.Close().get() == end, "decoder closing timestamp");
+    // a record batch of some other schema is refused, not misread
+    auto other = arrow::RecordBatch::Make(arrow::schema({arrow::field("x", arrow::int64())}), 0,
+                                          {std::make_shared<arrow::Int64Array>(0, nullptr)});
+    CHECK(!dec.PushRecordBatch(other), "foreign schema accepted");
   }
-  CHECK(dec.Close().get() == end, "decoder closing timestamp");
   CHECK(seen == n && bad == 0, "%zu of %zu images, %d bad", seen, n, bad);
   // FPV_ARROW_IPC_OUT=<path>: the record batches of this case as an Arrow IPC file, for a
   // consumer that is not this code base (tests/test_arrow.py reads it with pyarrow)

@@ -126,7 +126,7 @@ def main():
 
     # HIP-event timing on the launch stream: whole pipeline and per kernel
     ev_ms, kernel_ms = pred.time_predict(d_frames, out, max(args.steps, 5), per_kernel=True)
-    names = ["k_stream", "k_decide_spec", "redo_lists(2 launches)", "k_finish"]
+    names = ["k_stream", "k_redo_decide", "k_redo_stream", "-"]
     copy_gbps = pkg.copy_bandwidth_GBps(1 << 30, 5, device=local_rank) if rank == 0 else 0.0
     dom = int(np.argmax(kernel_ms))
     dom_s = kernel_ms[dom] / 1e3

@@ -281,6 +281,7 @@ int fpvhip_split_frame(fpvhip_ctx* c, const uint16_t* img, uint8_t* high, uint8_
     HIPOK(c, hipMemcpyAsync(low, s.d_low, np, hipMemcpyDeviceToHost, s.stream));
   uint32_t any = 0;
   HIPOK(c, hipMemcpyAsync(&any, s.ws.anylow, 4, hipMemcpyDeviceToHost, s.stream));
+  HIPOK(c, hipMemsetAsync(s.ws.anylow, 0, 4, s.stream));  // the predictor expects its accumulators clean
   HIPOK(c, hipStreamSynchronize(s.stream));
   *no_low = any == 0;
   return 0;
@@ -511,7 +512,7 @@ int fpvhip_warmup(int device) {
 int fpvhip_debug_counters(fpvhip_ctx* c, uint32_t* out, uint32_t n) {
   if (!c || !out || n > 64 || !c->g.fwd_ok) return fail(c, "bad arguments");
   HIPOK(c, hipDeviceSynchronize());
-  HIPOK(c, hipMemcpy(out, c->ws.counters, n * 4, hipMemcpyDeviceToHost));
+  HIPOK(c, hipMemcpy(out, c->ws.ctr + ((c->ws.seq + 1) & 1u) * 64, n * 4, hipMemcpyDeviceToHost));  // the last batch's block
   return 0;
 }
 

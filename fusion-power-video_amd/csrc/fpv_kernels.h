@@ -18,19 +18,16 @@ constexpr int kNumHists = 5;
 struct Geom {
   uint32_t xs, ys, npix;        // frame
   uint32_t pw, ph, npv;         // preview = (xs/4) x (ys/4)
-  uint32_t tile_rows, tile_px;  // forward kernel: rows per workgroup tile
-  uint32_t tiles;               // tiles per frame
-  uint32_t lds_off;             // byte offset of tile pixel 0 inside the line buffer
-  uint32_t lds_h_bytes;         // bytes of the high line buffer (16-aligned)
-  uint32_t lds_hist_off;        // byte offset of the 3 LDS histograms
-  uint32_t lds_bytes;           // total dynamic LDS of the forward kernel
   uint32_t strip_rows, strips;  // streaming kernel: rows per wave strip, strips per frame
+  uint32_t redo_strip_rows, redo_strips;  // the same for the redo pass of mis-speculated frames (shorter strips)
   uint32_t ring_fwd, ring_base; // streaming kernel: LDS ring size (pow2), offset of strip pixel 0
   uint32_t nacc;                // streaming kernel: preview accumulator rows
+  uint32_t pwr, pvb_stride;     // pw rounded up to 16; bytes of one (frame, strip) boundary record
   uint32_t wave_lds;            // streaming kernel: LDS bytes per wave
   uint32_t stream_waves_per_cu; // streaming kernel: persistent waves per CU
+  uint32_t wg_waves;            // streaming kernel: waves (= consecutive frames) per workgroup
+  uint32_t fast;                // streaming kernel: the FAST variant applies (xs % 64 == 0, full steps)
   uint32_t nd, ncg;             // sample counts of the two heuristics
-  uint32_t stat_blocks;         // workgroups per frame of the stats kernel
   uint32_t ring;                // inverse kernel: LDS ring size (power of two)
   uint32_t inv_ring;            // fast inverse kernel: ring size in pixels (power of two)
   uint32_t spec_k4;             // speculative inverse kernel: dwords (4 pixels) per lane and superstep, 0 = unusable
@@ -47,15 +44,17 @@ bool make_geom(uint32_t xs, uint32_t ys, int shift, int big_endian, Geom* g,
 bool make_geom_decoder(uint32_t xs, uint32_t ys, Geom* g, const char** why);
 
 struct FwdWorkspace {
-  uint32_t* anylow;    // [nframes]  OR of raw low bytes
-  uint32_t* counters;  // |list A|, |list B|, votes[4]
-  uint8_t* decision;   // [nframes]  bit0 delta, bit1 CG
-  uint32_t* list_a;    // frames whose delta decision was mis-speculated
-  uint32_t* list_b;    // frames to re-apply under their true flags
-  uint8_t* pv_raw;     // [nframes][npv] un-predicted preview
-  uint16_t* partials;  // [nframes][tiles][3][256] per-tile histograms of the fused pass
-  uint8_t* spec;       // speculated flags for the next batch
-  size_t zero_fixed;   // leading bytes that every batch zeroes (counters, anylow)
+  uint32_t* ctr;         // two counter blocks of 64 words (alternating batches): list sizes, task counters, votes
+  uint32_t* anylow;      // [nframes]  OR of raw low bytes
+  uint32_t* frame_done;  // [nframes]  strips of the frame that have finished
+  uint8_t* decision;     // [nframes]  bit0 delta, bit1 CG
+  uint32_t* list_a;      // frames whose delta decision was mis-speculated
+  uint32_t* list_b;      // frames to redo under their true flags
+  uint8_t* pvb;          // [nframes][strips] raw first / last preview row of every strip
+  uint16_t* partials;    // [nframes][strips][3][256] per-strip histograms of the fused pass
+  uint8_t* spec;         // speculated flags for the next batch
+  size_t zero_bytes;     // leading bytes cleared once at creation (counters, anylow, frame_done)
+  uint32_t seq;          // batches launched so far (selects the counter block); host side
 };
 size_t fwd_workspace_bytes(const Geom& g, uint32_t nframes);
 void carve_fwd_workspace(const Geom& g, uint32_t nframes, void* base,
@@ -82,10 +81,11 @@ hipError_t launch_split_decoded(const Geom& g, const uint16_t* d_img,
                                 uint8_t* d_high, uint8_t* d_low, hipStream_t s);
 
 // Forward predictor for nframes frames.  ev, when non-null, points to 5 events
-// recorded around [fused, decide, redo x3, finish] (timing pass).
+// recorded around [k_stream, k_redo_decide, k_redo_stream, -] (timing pass).
+// One workspace serves one stream at a time (its batch counter lives in ws).
 hipError_t launch_predict(const Geom& g, const uint16_t* d_frames,
                           uint32_t nframes, const uint8_t* d_dhigh,
-                          const uint8_t* d_dlow, const FwdWorkspace& ws,
+                          const uint8_t* d_dlow, FwdWorkspace& ws,
                           uint8_t* d_high, uint8_t* d_low, uint8_t* d_preview,
                           uint8_t* d_flags, hipStream_t s, hipEvent_t* ev);
 

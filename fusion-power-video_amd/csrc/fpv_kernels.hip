@@ -64,14 +64,19 @@ __device__ __forceinline__ void split4(uint32_t va, uint32_t vb, int S,
     *h4 = __builtin_amdgcn_perm(hb, ha, 0x06040200u);
     *l4 = __builtin_amdgcn_perm(lb, la, 0x06040200u);
   } else {
-    const uint32_t m = (0xffffu >> S) * 0x00010001u;
-    uint32_t qa = (va & m) << S, qb = (vb & m) << S;
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    const us2 sh = {(unsigned short)S, (unsigned short)S};  // v_pk_lshlrev_b16: (uint16_t)(p << S), two pixels per op
+    const uint32_t qa = __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2, va) << sh);
+    const uint32_t qb = __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2, vb) << sh);
     *h4 = __builtin_amdgcn_perm(qb, qa, 0x07050301u);
     *l4 = __builtin_amdgcn_perm(qb, qa, 0x06040200u);
   }
 }
 
 // Per-byte a - b (mod 256) on 4 packed bytes (std::minus<uint8_t>, cc:534-537).
+// (Byte-addressed SDWA subtractions into one register would take 3 ops instead of 5,
+// but partial-register writes need wait states the compiler cannot see inside inline
+// asm on gfx950: measured wrong results.  Plain SWAR it stays.)
 __device__ __forceinline__ uint32_t sub4(uint32_t a, uint32_t b) {
   const uint32_t H = 0x80808080u;
   return ((a | H) - (b & ~H)) ^ ((a ^ ~b) & H);
@@ -91,16 +96,6 @@ __device__ __forceinline__ int cg_pred(int n, int w, int nw) {
 
 __device__ __forceinline__ uint32_t byte_of(uint32_t v, int k) {
   return (v >> (8 * k)) & 0xffu;
-}
-
-// Sum over the 256 threads of a block; every thread gets the result.
-__device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t* scratch) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  __syncthreads();  // scratch may still be read from a previous call
-  if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
-  __syncthreads();
-  return scratch[0] + scratch[1] + scratch[2] + scratch[3];
 }
 
 // Streaming copy, 16 B per lane, non-temporal, one contiguous 256 KiB chunk per
@@ -204,228 +199,40 @@ __global__ __launch_bounds__(kThreads) void k_unextract(uint16_t* __restrict__ p
 // frame before it transforms it.  A second read of every frame would cost a
 // third of the HBM traffic, so the forward path SPECULATES:
 //
-//   k_stream       one pass per frame: split, preview, delta and CG residuals
-//                  under the speculated flags, AND the exact histograms of the
-//                  heuristics for that speculation, written as per-strip partials
-//   k_decide_spec  reduces the partials, evaluates EstimateEntropy, compares
-//                  the true decision with the speculation; mis-speculated
-//                  frames go to list A (delta decision wrong: histograms of the
-//                  CG decision are void) or list B (only the CG decision wrong)
-//   k_redo_decide / k_apply_list
-//                  exact, non-speculative redo of the listed frames (normally
-//                  none: these launches exit at once)
-//   k_finish       preview clamped gradient, flags byte, next speculation
+//   k_stream       one pass per frame, strip by strip (one wavefront per strip):
+//                  split, preview (with its clamped gradient), delta and CG
+//                  residuals under the speculated flags, AND the exact histograms
+//                  of the heuristics for that speculation.  The wave that finishes
+//                  a frame's LAST strip reduces the strips' histograms, evaluates
+//                  EstimateEntropy, compares the true decision with the speculation
+//                  and either finalises the frame (flags byte, the preview rows on
+//                  strip boundaries) or puts it on list A (delta decision wrong:
+//                  the CG histograms are void) or list B (only the CG decision wrong)
+//   k_redo_decide  exact decisions of list A from the heuristics' samples
+//   k_redo_stream  the same strip pass under the TRUE flags for list B; also
+//                  publishes the next batch's speculation (majority vote)
 //
-// The speculation only ever changes speed: every frame's output is produced
-// under its TRUE flags.
+// Normally both lists are empty and the two redo launches exit at once.  The
+// speculation only ever changes speed: every frame's output is produced under
+// its TRUE flags.
 
-constexpr int kMaxIter = 8;        // passes of 256 threads x 16 pixels over a redo tile (bounds its LDS: xsize <= 8192)
-constexpr int kHistFused = 3;      // partial histograms per tile: d, a, b
-constexpr int kListGrid = 1024;    // workgroups of the list-driven kernels
+constexpr int kHistFused = 3;      // partial histograms per strip: d, a, b
+constexpr uint32_t kStep = 1024;   // pixels per wave step
+#ifndef FPV_DEPTH
+#define FPV_DEPTH 3
+#endif
+constexpr int kDepth = FPV_DEPTH;  // steps of pixel / delta loads in flight per wave
 
-// Tile geometry shared by the tile routines.
-struct TileCtx {
-  uint32_t s, npx, nseg, rows, row0;
+// Workspace counter block (u32 words).  Two blocks alternate between batches: a
+// batch's first kernel clears the other block, so no memset launch is needed.
+enum : uint32_t {
+  kCtrListA = 0,     // |list A|
+  kCtrListB = 1,     // |list B|
+  kCtrTask = 2,      // k_stream's task counter
+  kCtrRedoTask = 3,  // k_redo_stream's task counter
+  kCtrVotes = 4,     // [4] decisions seen, by value
+  kCtrWords = 16
 };
-
-__device__ __forceinline__ TileCtx tile_ctx(const Geom& g, uint32_t tile) {
-  TileCtx t;
-  t.row0 = tile * g.tile_rows;
-  t.rows = min(g.tile_rows, g.ys - t.row0);
-  t.s = t.row0 * g.xs;
-  t.npx = t.rows * g.xs;
-  t.nseg = t.npx >> 4;
-  return t;
-}
-
-// Dynamic LDS layout of the tile routines:
-//   [0, lds_h_bytes)            high line buffer: halo (xs+16 bytes in front of
-//                               lds_off) + the tile's post-delta high bytes
-//   [lds_h_bytes, +tile_px/2)   4-pixel sums of the raw high bytes (u16)
-//   then 3 x 256 u32            histograms (fused kernel)
-//   last 16 bytes               OR of the raw low bytes
-struct TileLds {
-  uint8_t* hbuf;
-  uint16_t* psum;
-  uint32_t* hist;
-  uint32_t* s_or;
-};
-
-__device__ __forceinline__ TileLds tile_lds(uint8_t* smem, const Geom& g) {
-  TileLds l;
-  l.hbuf = smem;
-  l.psum = reinterpret_cast<uint16_t*>(smem + g.lds_h_bytes);
-  l.hist = reinterpret_cast<uint32_t*>(smem + g.lds_hist_off);
-  l.s_or = reinterpret_cast<uint32_t*>(smem + g.lds_bytes - 16);
-  return l;
-}
-
-// Halo: post-delta high bytes of the xs+16 pixels in front of the tile, 4 per
-// thread and step.  dcache: this thread's cached delta-high dwords (or null).
-template <bool SWAP>
-__device__ __forceinline__ void load_halo(const Geom& g, const TileCtx& t, const TileLds& L,
-                                          const uint16_t* img, const uint8_t* dhigh,
-                                          bool use_delta) {
-  const uint32_t hs = t.s - g.xs - 16, ngrp = (g.xs + 16) >> 2;
-  for (uint32_t k = threadIdx.x; k < ngrp; k += kThreads) {
-    const uint2 v = *reinterpret_cast<const uint2*>(img + hs + 4 * k);
-    uint32_t h4, l4;
-    split4<SWAP>(v.x, v.y, g.shift, &h4, &l4);
-    if (use_delta) h4 = sub4(h4, *reinterpret_cast<const uint32_t*>(dhigh + hs + 4 * k));
-    *reinterpret_cast<uint32_t*>(L.hbuf + g.lds_off - (g.xs + 16) + 4 * k) = h4;
-  }
-}
-
-// Phase A for one 16-pixel segment: split, preview sums, NO_LOW OR, optional
-// histogram sample of the raw high byte (i % 15 == 0), delta, low plane store,
-// high bytes into LDS (and to global when CG is off).
-template <bool SWAP, bool STATS>
-__device__ __forceinline__ void seg_phase_a(const Geom& g, const TileCtx& t, const TileLds& L,
-                                            uint32_t o, const uint4& pa, const uint4& pb,
-                                            const uint4& dh, const uint4& dl, bool use_delta,
-                                            bool use_cg, uint8_t* high_f, uint8_t* low_f,
-                                            uint32_t* or_low) {
-  const int S = g.shift;
-  uint4 h, l;
-  split4<SWAP>(pa.x, pa.y, S, &h.x, &l.x);
-  split4<SWAP>(pa.z, pa.w, S, &h.y, &l.y);
-  split4<SWAP>(pb.x, pb.y, S, &h.z, &l.z);
-  split4<SWAP>(pb.z, pb.w, S, &h.w, &l.w);
-  uint2 ps;  // cc:500-509: sums of 4 consecutive RAW high bytes
-  ps.x = __builtin_amdgcn_sad_u8(h.x, 0, 0) | (__builtin_amdgcn_sad_u8(h.y, 0, 0) << 16);
-  ps.y = __builtin_amdgcn_sad_u8(h.z, 0, 0) | (__builtin_amdgcn_sad_u8(h.w, 0, 0) << 16);
-  *reinterpret_cast<uint2*>(L.psum + (o >> 2)) = ps;
-  if (S != 8) *or_low |= l.x | l.y | l.z | l.w;  // RAW low bytes (cc:396, 414, 426, 442)
-  if (STATS) {  // cc:526-531: counta of high[0::15]
-    const uint32_t m = (t.s + o) % 15u;
-    const uint32_t j0 = m ? 15u - m : 0u;  // 0..14: first sampled pixel of the segment
-    const uint32_t d = j0 >> 2;
-    uint32_t v = d == 0 ? h.x : d == 1 ? h.y : d == 2 ? h.z : h.w;
-    atomicAdd(&L.hist[(v >> (8 * (j0 & 3))) & 0xffu], 1u);
-    if (j0 == 0) atomicAdd(&L.hist[h.w >> 24], 1u);  // pixel 15 of the segment
-  }
-  if (use_delta) {  // cc:534-537
-    h.x = sub4(h.x, dh.x); h.y = sub4(h.y, dh.y);
-    h.z = sub4(h.z, dh.z); h.w = sub4(h.w, dh.w);
-    if (S != 8) {
-      l.x = sub4(l.x, dl.x); l.y = sub4(l.y, dl.y);
-      l.z = sub4(l.z, dl.z); l.w = sub4(l.w, dl.w);
-    }
-  }
-  if (S != 8) *reinterpret_cast<uint4*>(low_f + t.s + o) = l;
-  *reinterpret_cast<uint4*>(L.hbuf + g.lds_off + o) = h;
-  if (!use_cg) *reinterpret_cast<uint4*>(high_f + t.s + o) = h;
-}
-
-// Phase B for one segment: clamped-gradient residuals (cc:566-572) from the LDS
-// line buffer and, with STATS, the CG heuristic's sample (cc:554-562).
-template <bool STATS>
-__device__ __forceinline__ void seg_phase_b(const Geom& g, const TileCtx& t, const TileLds& L,
-                                            uint32_t o, bool use_cg, uint8_t* high_f) {
-  const uint8_t* cp = L.hbuf + g.lds_off + o;
-  if (use_cg) {
-    const uint8_t* np = cp - g.xs;
-    uint32_t c[5], n[5];
-    c[0] = *reinterpret_cast<const uint32_t*>(cp - 4);
-    const uint4 cv = *reinterpret_cast<const uint4*>(cp);
-    c[1] = cv.x; c[2] = cv.y; c[3] = cv.z; c[4] = cv.w;
-#pragma unroll
-    for (int k = 0; k < 5; k++) n[k] = *reinterpret_cast<const uint32_t*>(np - 4 + 4 * k);
-    uint32_t out[4];
-    int wprev = (int)byte_of(c[0], 3), nwprev = (int)byte_of(n[0], 3);
-    const bool lit = t.s + o < g.xs + 1;  // segment reaches into the literal prefix (cc:572)
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      uint32_t r = 0;
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const int x = (int)byte_of(c[k + 1], j), nn = (int)byte_of(n[k + 1], j);
-        int res = (x - cg_pred(nn, wprev, nwprev)) & 0xff;
-        if (lit && t.s + o + 4 * k + j < g.xs + 1) res = x;
-        r |= (uint32_t)res << (8 * j);
-        wprev = x;
-        nwprev = nn;
-      }
-      out[k] = r;
-    }
-    *reinterpret_cast<uint4*>(high_f + t.s + o) = make_uint4(out[0], out[1], out[2], out[3]);
-  }
-  if (STATS) {  // samples at i = xs + 1 + 31 k
-    const int q = (int)(t.s + o) - (int)(g.xs + 1);
-    uint32_t j1;
-    if (q >= 0) {
-      const uint32_t r = (uint32_t)q % 31u;
-      j1 = r ? 31u - r : 0u;
-    } else {
-      j1 = (uint32_t)(-q);
-    }
-    if (j1 < 16) {
-      const uint8_t* p = cp + j1;
-      const int x = p[0], w = p[-1], n = p[-(int)g.xs], nw = p[-(int)g.xs - 1];
-      atomicAdd(&L.hist[256 + x], 1u);
-      atomicAdd(&L.hist[512 + ((x - cg_pred(n, w, nw)) & 0xff)], 1u);
-    }
-  }
-}
-
-// 4x4 preview boxes of the tile from the 4-pixel sums (cc:500-512).
-__device__ __forceinline__ void tile_preview(const Geom& g, const TileCtx& t, const TileLds& L,
-                                             uint8_t* pv_f) {
-  const uint32_t xq = g.xs >> 2;  // psum entries per image row
-  uint8_t* pvo = pv_f + (size_t)(t.row0 >> 2) * g.pw;
-  if ((g.pw & 3) == 0) {  // 4 preview pixels per thread: 8-byte LDS reads, one dword store
-    const uint32_t pw4 = g.pw >> 2, ngrp = (t.rows >> 2) * pw4;
-    for (uint32_t q = threadIdx.x; q < ngrp; q += kThreads) {
-      const uint32_t pr = q / pw4, pc = (q - pr * pw4) << 2;
-      const uint16_t* p = L.psum + pr * g.xs + pc;
-      uint2 a = *reinterpret_cast<const uint2*>(p);
-#pragma unroll
-      for (int r = 1; r < 4; r++) {
-        const uint2 b = *reinterpret_cast<const uint2*>(p + r * xq);
-        a.x += b.x;  // 16-bit lanes cannot overflow: 16 * 255 < 65536
-        a.y += b.y;
-      }
-      a.x = (a.x >> 4) & 0x00fe00feu;
-      a.y = (a.y >> 4) & 0x00fe00feu;
-      *reinterpret_cast<uint32_t*>(pvo + pr * g.pw + pc) = __builtin_amdgcn_perm(a.y, a.x, 0x06040200u);
-    }
-  } else {
-    const uint32_t npq = (t.rows >> 2) * g.pw;
-    for (uint32_t q = threadIdx.x; q < npq; q += kThreads) {
-      const uint32_t pr = q / g.pw, pc = q - pr * g.pw;
-      const uint16_t* p = L.psum + pr * g.xs + pc;
-      pvo[q] = (uint8_t)(((p[0] + p[xq] + p[2 * xq] + p[3 * xq]) >> 4) & 0xfe);
-    }
-  }
-}
-
-__device__ __forceinline__ void tile_or_low(const TileLds& L, uint32_t or_low) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) or_low |= __shfl_xor(or_low, off, 64);
-  if ((threadIdx.x & 63) == 0 && or_low) atomicOr(L.s_or, or_low);
-}
-
-// ---------------------------------------------------------------------------
-// k_stream: the fused speculative pass as a barrier-free streaming kernel.
-//
-// One WAVEFRONT owns one strip (strip_rows image rows) of one frame at a time
-// and pulls strips from a device-side counter.  Per step the wave handles 1024
-// consecutive pixels of the flattened plane, 16 per lane:
-//   - 32-byte coalesced pixel loads (and the delta bytes) come from a 3-deep
-//     register prefetch pipeline: the loads of step t+3 are issued when step t
-//     has consumed its registers, so each wave keeps ~6 KiB of HBM reads in
-//     flight and no load is waited for right after its issue;
-//   - the post-delta high bytes go into the wave's private LDS ring (the last
-//     xs+16+1024 bytes of the plane): the clamped gradient reads its north /
-//     north-west / west neighbours from there.  One wave executes its LDS
-//     operations in order, so no barrier is needed;
-//   - the 4x4 preview boxes are accumulated with LDS adds, one accumulator
-//     row per 4-row group, and written when a group is complete;
-//   - the heuristic samples (i % 15 == 0; i = xs+1+31k) are counted in the
-//     wave's LDS histograms (16-bit bins packed in dwords).
-// ---------------------------------------------------------------------------
-
-constexpr uint32_t kStep = 1024;  // pixels per wave step
 
 // Streaming accesses: pixels are read once and planes are written once, so they
 // are marked non-temporal to keep the (re-used) delta planes resident in L2.
@@ -448,6 +255,34 @@ __device__ __forceinline__ void st_stream(void* p, uint4 v) {
 #else
   *reinterpret_cast<uint4*>(p) = v;
 #endif
+}
+
+// Hand-off accesses (strip -> the wave that finalises the frame, possibly on
+// another XCD): agent-scope relaxed atomics = write-through `sc1` stores and
+// L1-bypassing `sc1` loads.  The producer drains them (s_waitcnt vmcnt(0)) before
+// its arrival atomic; the consumer runs an agent-scope acquire after its own.
+__device__ __forceinline__ void st_agent64(void* p, uint64_t v) {
+  __hip_atomic_store(reinterpret_cast<uint64_t*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint64_t ld_agent64(const void* p) {
+  return __hip_atomic_load(reinterpret_cast<const uint64_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t ld_agent32(const void* p) {
+  return __hip_atomic_load(reinterpret_cast<const uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent8(uint8_t* p, uint8_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t ld_agent8(const uint8_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent128(void* p, uint4 v) {
+  st_agent64(p, (uint64_t)v.x | ((uint64_t)v.y << 32));
+  st_agent64(static_cast<uint8_t*>(p) + 8, (uint64_t)v.z | ((uint64_t)v.w << 32));
+}
+__device__ __forceinline__ uint4 ld_agent128(const void* p) {
+  const uint64_t a = ld_agent64(p), b = ld_agent64(static_cast<const uint8_t*>(p) + 8);
+  return make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
 }
 
 typedef short pk16 __attribute__((ext_vector_type(2)));  // two 16-bit lanes in one VGPR
@@ -484,9 +319,28 @@ __device__ __forceinline__ uint32_t cg_res4(uint32_t cur, uint32_t north, uint32
   return __builtin_amdgcn_perm(ro, re, 0x06020400u);                 // low bytes, pixel order
 }
 
+// Residuals of 16 pixels; wprev / nwprev: the dwords in front of cur / north.
+__device__ __forceinline__ uint4 cg_res16(uint4 cur, uint4 north, uint32_t wprev, uint32_t nwprev) {
+  uint32_t xo_prev = __builtin_amdgcn_perm(0, wprev, 0x0c030c01u);
+  uint32_t no_prev = __builtin_amdgcn_perm(0, nwprev, 0x0c030c01u);
+  uint4 r;
+  r.x = cg_res4(cur.x, north.x, &xo_prev, &no_prev);
+  r.y = cg_res4(cur.y, north.y, &xo_prev, &no_prev);
+  r.z = cg_res4(cur.z, north.z, &xo_prev, &no_prev);
+  r.w = cg_res4(cur.w, north.w, &xo_prev, &no_prev);
+  return r;
+}
+
 struct Pre {  // prefetch registers of one step
   uint4 a, b, dh, dl;
 };
+
+// Diagnostic builds only (-DFPV_ABL=<bits>, never the shipped binary): leave parts of the
+// step out to see what they cost.  1 CG arithmetic, 2 ring reads + CG, 4 heuristic samples,
+// 8 preview adds + rows, 16 delta subtraction, 32 low-plane store, 64 high-plane store.
+#ifndef FPV_ABL
+#define FPV_ABL 0
+#endif
 
 #ifdef FPV_STAMPS
 #define FPV_STAMP(k)                                                                      \
@@ -502,6 +356,32 @@ struct Pre {  // prefetch registers of one step
 #define FPV_STAMP(k)
 #endif
 
+// Kernel arguments kept small on purpose: everything else is derived.
+struct StreamArgs {
+  uint32_t xs, ys, npix, pw, npv;
+  uint32_t strip_rows, strips, ring_fwd, ring_base, nacc, shift, nframes, strip_major;
+  uint32_t pwr;         // pw rounded up to 16: bytes of one boundary preview row
+  uint32_t pvb_stride;  // bytes of one (frame, strip) boundary record: first row | last row | 8
+  uint32_t with_delta;  // a delta frame exists
+  uint32_t wave_lds;    // LDS bytes of one wave
+  uint32_t wg_waves;    // waves (= consecutive frames) per workgroup of k_stream
+};
+
+// Device pointers of one forward launch.
+struct StreamPtrs {
+  const uint16_t* frames;
+  const uint8_t *dhigh, *dlow;
+  uint8_t *high, *low, *preview, *flags;
+  uint32_t *anylow, *frame_done;
+  uint16_t* partials;
+  uint8_t* pvb;        // boundary preview rows (raw) of every (frame, strip)
+  uint32_t* ctr;       // this batch's counter block
+  uint32_t* ctr_next;  // the next batch's (cleared here)
+  uint8_t* decision;
+  uint32_t *list_a, *list_b;
+  uint8_t* spec;       // speculation byte: read by k_stream, written by k_redo_stream
+};
+
 struct StreamCtx {
 #ifdef FPV_STAMPS
   unsigned long long seg[6], tlast;
@@ -509,19 +389,25 @@ struct StreamCtx {
   // constant per kernel
   uint32_t lane, xs, pw, ring_mask, ring_base, nacc, shift;
   uint8_t* ring;
-  uint32_t* acc;     // [nacc][pw] preview accumulators
-  uint32_t* hist;    // [3][128] packed 16-bit bins
-  bool use_delta, use_cg;
+  uint32_t* acc;     // preview accumulators: FAST [2][4][pw/4] (transposed), else [nacc][pw]
+  uint32_t* hist;    // [3][256] bins
+  uint8_t* pvprev;   // previous raw preview row (north of the next one)
   // per strip
+  bool use_delta, use_cg;
   uint32_t s, npx;   // first pixel (frame-flat) and pixel count of the strip
   const uint16_t* img;
   const uint8_t *dh, *dl;
   uint8_t *high_f, *low_f, *pv_f;
+  uint8_t* rec;      // this strip's boundary record
+  uint32_t pwr;
   uint32_t row, col; // position of this lane's segment relative to the strip start
-  uint32_t m15;      // (frame-flat index of the segment) mod 15
-  int q31;           // index - (xs + 1): negative in front of the first CG sample, else mod 31
+  uint32_t drow, dcol; // kStep / xs, kStep % xs
+  uint32_t j0;       // offset of the segment's first delta-heuristic sample (index % 15 == 0): 0..14
+  uint32_t j1;       // offset of the next index congruent to xs + 1 (mod 31): 0..30
   uint32_t or_low;
-  uint32_t groups_done, prow0;
+  uint32_t groups_done, prow0, prows;  // preview rows of the strip: written, first (absolute), count
+  uint32_t wlast, wlast2;              // last raw preview pixel of the previous row / the one before
+  bool first_strip, last_strip;
 };
 
 __device__ __forceinline__ uint32_t ring_at(const StreamCtx& c, int o) {
@@ -529,10 +415,24 @@ __device__ __forceinline__ uint32_t ring_at(const StreamCtx& c, int o) {
 }
 
 __device__ __forceinline__ void hist_inc(uint32_t* hist, uint32_t which, uint32_t bin) {
-  atomicAdd(&hist[which * 128 + (bin >> 1)], 1u << (16 * (bin & 1)));
+  atomicAdd(&hist[which * 256 + bin], 1u);
 }
 
-// DELTA / LOW are the (wave-uniform) conditions "delta predictor speculated" and
+// Byte j (0..15) of 16 bytes held in four dwords, without a branch or a lane mask:
+// a byte permute of each 8-byte half, merged by a bit-field insert on bit 3 of j.
+struct ByteSel { uint32_t sel, mask; };
+__device__ __forceinline__ ByteSel byte_sel(uint32_t j) {
+  ByteSel b;
+  b.sel = (j & 7u) | 0x0c0c0c00u;                                   // v_perm selector: byte j & 7, zeros above
+  b.mask = (uint32_t)__builtin_amdgcn_sbfe((int)j, 3, 1);          // all ones when j >= 8
+  return b;
+}
+__device__ __forceinline__ uint32_t byte16(const uint4& v, const ByteSel& b) {
+  const uint32_t lo = __builtin_amdgcn_perm(v.y, v.x, b.sel), hi = __builtin_amdgcn_perm(v.w, v.z, b.sel);
+  return (hi & b.mask) | (lo & ~b.mask);
+}
+
+// DELTA / LOW are the (wave-uniform) conditions "delta predictor applied" and
 // "a low plane exists" as template parameters, and FAST steps are always full:
 // no control flow around the loads, so that the compiler can keep the three
 // prefetch stages in flight with counted vmcnt waits.
@@ -562,31 +462,114 @@ __device__ __forceinline__ void stream_load(const StreamCtx& c, uint32_t it, uin
   }
 }
 
-// Writes the finished 4-row groups' preview pixels and clears their accumulators.
-__device__ __forceinline__ void stream_preview_flush(StreamCtx& c, uint32_t upto_groups) {
-  while (c.groups_done < upto_groups) {
-    const uint32_t slot = c.nacc == 2 ? (c.groups_done & 1u) : c.groups_done % c.nacc;
-    uint32_t* a = c.acc + slot * c.pw;
-    uint8_t* out = c.pv_f + (size_t)(c.prow0 + c.groups_done) * c.pw;
-    if ((c.pw & 3) == 0) {
-      for (uint32_t k = c.lane * 4; k < c.pw; k += 256) {
-        const uint4 v = *reinterpret_cast<const uint4*>(a + k);
-        *reinterpret_cast<uint4*>(a + k) = make_uint4(0, 0, 0, 0);
-        *reinterpret_cast<uint32_t*>(out + k) = ((v.x >> 4) & 0xfeu) | (((v.y >> 4) & 0xfeu) << 8) |
-                                                (((v.z >> 4) & 0xfeu) << 16) | (((v.w >> 4) & 0xfeu) << 24);
+// One finished preview row (cc:500-512 then cc:575-586): (sum / 16) & 0xfe of the
+// 4x4 boxes from the accumulators, the clamped gradient against the previous raw
+// row (kept in LDS) when CG is applied, accumulators cleared.  Rows whose north
+// row belongs to another strip (the first row of strips > 0) cannot be predicted
+// here: their raw bytes go to the strip's boundary record, as do the raw bytes of
+// the strip's last row, and the wave that finalises the frame predicts them.
+template <bool FAST>
+__device__ __forceinline__ void preview_row_out(StreamCtx& c) {
+  const uint32_t r = c.prow0 + c.groups_done;  // absolute preview row
+  const bool first_row = c.groups_done == 0, last_row = c.groups_done + 1 == c.prows;
+  const bool defer = c.use_cg && first_row && !c.first_strip;
+  const bool rec_last = c.use_cg && last_row && !c.last_strip;
+  const bool predict = c.use_cg && r > 0 && !defer;
+  uint8_t* out = c.pv_f + (size_t)r * c.pw;
+  uint32_t newlast = 0;
+  if (FAST) {  // pw % 16 == 0: 8 preview pixels per lane, transposed accumulators
+    const uint32_t q4 = c.pw >> 2;
+    uint32_t* a = c.acc + (c.groups_done & (c.nacc - 1)) * c.pw;
+    uint32_t carry_w = c.wlast << 24, carry_nw = c.wlast2 << 24;
+    for (uint32_t k0 = 0; k0 < c.pw; k0 += 512) {
+      const uint32_t k = k0 + c.lane * 8;
+      const bool act = k < c.pw;
+      uint2 cur = make_uint2(0, 0), north = make_uint2(0, 0);
+      if (act) {
+        uint2 sj[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          sj[j] = *reinterpret_cast<const uint2*>(a + j * q4 + (k >> 2));
+          *reinterpret_cast<uint2*>(a + j * q4 + (k >> 2)) = make_uint2(0, 0);
+        }
+        // dword d holds preview pixels k + 4 d .. k + 4 d + 3 = plane 0..3 of quad d
+        auto pack = [](uint32_t s0, uint32_t s1, uint32_t s2, uint32_t s3) {
+          const uint32_t t01 = ((s0 | (s1 << 16)) >> 4) & 0x00fe00feu;
+          const uint32_t t23 = ((s2 | (s3 << 16)) >> 4) & 0x00fe00feu;
+          return __builtin_amdgcn_perm(t23, t01, 0x06040200u);
+        };
+        cur.x = pack(sj[0].x, sj[1].x, sj[2].x, sj[3].x);
+        cur.y = pack(sj[0].y, sj[1].y, sj[2].y, sj[3].y);
+        if (c.use_cg) {
+          north = *reinterpret_cast<const uint2*>(c.pvprev + k);
+          *reinterpret_cast<uint2*>(c.pvprev + k) = cur;
+        }
       }
-    } else {
-      for (uint32_t k = c.lane; k < c.pw; k += 64) {
-        out[k] = (uint8_t)((a[k] >> 4) & 0xfeu);
-        a[k] = 0;
+      uint32_t wprev = (uint32_t)__shfl_up((int)cur.y, 1, 64), nwprev = (uint32_t)__shfl_up((int)north.y, 1, 64);
+      if (c.lane == 0) { wprev = carry_w; nwprev = carry_nw; }
+      carry_w = (uint32_t)__builtin_amdgcn_readlane((int)cur.y, 63);
+      carry_nw = (uint32_t)__builtin_amdgcn_readlane((int)north.y, 63);
+      if (k0 + 512 >= c.pw)  // the row's last pixel: byte 3 of the last active lane's last dword
+        newlast = (uint32_t)__builtin_amdgcn_readlane((int)cur.y, (int)((c.pw - 1 - k0) >> 3)) >> 24;
+      if (act) {
+        uint2 res = cur;
+        if (predict) {
+          uint32_t xo_prev = __builtin_amdgcn_perm(0, wprev, 0x0c030c01u);
+          uint32_t no_prev = __builtin_amdgcn_perm(0, nwprev, 0x0c030c01u);
+          res.x = cg_res4(cur.x, north.x, &xo_prev, &no_prev);
+          res.y = cg_res4(cur.y, north.y, &xo_prev, &no_prev);
+          if (r == 1 && k == 0) res.x = (res.x & 0xffffff00u) | (cur.x & 0xffu);  // pixel pw is a literal (cc:575)
+        }
+        const uint64_t raw = (uint64_t)cur.x | ((uint64_t)cur.y << 32);
+        if (defer) st_agent64(c.rec + k, raw);
+        else *reinterpret_cast<uint2*>(out + k) = res;
+        if (rec_last) st_agent64(c.rec + c.pwr + k, raw);
       }
     }
-    c.groups_done++;
+  } else {  // any width: one preview pixel per lane and round
+    uint32_t* a = c.acc + (c.groups_done % c.nacc) * c.pw;
+    uint32_t carry_w = c.wlast, carry_nw = c.wlast2;
+    for (uint32_t k0 = 0; k0 < c.pw; k0 += 64) {
+      const uint32_t k = k0 + c.lane;
+      const bool act = k < c.pw;
+      uint32_t x = 0, n = 0;
+      if (act) {
+        x = (a[k] >> 4) & 0xfeu;
+        a[k] = 0;
+        if (c.use_cg) {
+          n = c.pvprev[k];
+          c.pvprev[k] = (uint8_t)x;
+        }
+      }
+      uint32_t w = (uint32_t)__shfl_up((int)x, 1, 64), nw = (uint32_t)__shfl_up((int)n, 1, 64);
+      if (c.lane == 0) { w = carry_w; nw = carry_nw; }
+      carry_w = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+      carry_nw = (uint32_t)__builtin_amdgcn_readlane((int)n, 63);
+      if (k0 + 64 >= c.pw) newlast = (uint32_t)__builtin_amdgcn_readlane((int)x, (int)(c.pw - 1 - k0));
+      if (act) {
+        uint32_t res = x;
+        if (predict && !(r == 1 && k == 0)) res = (x - (uint32_t)cg_pred((int)n, (int)w, (int)nw)) & 0xffu;
+        if (defer) st_agent8(c.rec + k, (uint8_t)x);
+        else out[k] = (uint8_t)res;
+        if (rec_last) st_agent8(c.rec + c.pwr + k, (uint8_t)x);
+      }
+    }
   }
+  // the last pixel of the row before this one: north-west of the next strip's first pixel
+  if (rec_last && c.lane == 0) st_agent64(c.rec + 2 * c.pwr, (uint64_t)c.wlast);
+  c.wlast2 = c.wlast;
+  c.wlast = newlast;
+  c.groups_done++;
 }
 
-// FAST: xs % 16 == 0 and xs >= 256 (a segment never straddles image rows, two
-// preview accumulator rows suffice, the north bytes are one aligned 16-byte read).
+template <bool FAST>
+__device__ __forceinline__ void stream_preview_flush(StreamCtx& c, uint32_t upto_groups) {
+  while (c.groups_done < upto_groups) preview_row_out<FAST>(c);
+}
+
+// FAST: xs % 64 == 0 and xs >= 256 (a segment never straddles image rows, two or four
+// preview accumulator rows suffice, the north bytes are one aligned 16-byte read,
+// a preview row is a whole number of 16-byte groups).
 template <bool SWAP, bool FAST, bool DELTA, bool LOW>
 __device__ __forceinline__ void stream_step(StreamCtx& c, uint32_t it, const Pre& p) {
   const uint32_t o = it * kStep + c.lane * 16;
@@ -603,13 +586,16 @@ __device__ __forceinline__ void stream_step(StreamCtx& c, uint32_t it, const Pre
 #endif
     FPV_STAMP(1);  // wait for the pixel loads + split
     // preview: 4-pixel sums of the RAW high bytes into the group accumulators (cc:500-509)
-    {
+    if (!(FPV_ABL & 8)) {
       const uint32_t q[4] = {__builtin_amdgcn_sad_u8(h.x, 0, 0), __builtin_amdgcn_sad_u8(h.y, 0, 0),
                              __builtin_amdgcn_sad_u8(h.z, 0, 0), __builtin_amdgcn_sad_u8(h.w, 0, 0)};
       if (FAST) {
-        uint32_t* a = c.acc + ((c.row >> 2) & 1u) * c.pw + (c.col >> 2);
+        // transposed: plane j holds quad j of every 16-pixel segment, so the 64 lanes of
+        // one add hit 64 consecutive dwords (no bank conflicts)
+        const uint32_t q4 = c.pw >> 2;
+        uint32_t* a = c.acc + ((c.row >> 2) & (c.nacc - 1)) * c.pw + (c.col >> 4);
 #pragma unroll
-        for (int j = 0; j < 4; j++) atomicAdd(a + j, q[j]);
+        for (int j = 0; j < 4; j++) atomicAdd(a + j * q4, q[j]);
       } else {
         uint32_t row = c.row, col = c.col;
 #pragma unroll
@@ -621,17 +607,15 @@ __device__ __forceinline__ void stream_step(StreamCtx& c, uint32_t it, const Pre
       }
     }
     if (LOW) c.or_low |= l.x | l.y | l.z | l.w;  // RAW low bytes: NO_LOW_BYTES (cc:447)
-    {  // cc:526-531: histogram of high[0::15]
-      const uint32_t j0 = c.m15 ? 15u - c.m15 : 0u;
-      const uint32_t d = j0 >> 2;
-      const uint32_t v = d == 0 ? h.x : d == 1 ? h.y : d == 2 ? h.z : h.w;
-      hist_inc(c.hist, 0, (v >> (8 * (j0 & 3))) & 0xffu);
-      if (j0 == 0) hist_inc(c.hist, 0, h.w >> 24);
-      c.m15 += kStep % 15u;
-      if (c.m15 >= 15u) c.m15 -= 15u;
+    if (!(FPV_ABL & 4)) {  // cc:526-531: histogram of high[0::15]
+      // j0 = offset of the segment's first sample (0..14); a second one (offset 15) iff j0 == 0
+      hist_inc(c.hist, 0, byte16(h, byte_sel(c.j0)));
+      atomicAdd(&c.hist[h.w >> 24], (c.j0 - 1u) >> 31);            // adds 1 iff j0 == 0
+      const int t = (int)c.j0 - (int)(kStep % 15u);                // the next segment starts kStep pixels on
+      c.j0 = (uint32_t)(t + ((t >> 31) & 15));
     }
     FPV_STAMP(2);  // preview adds + delta-histogram sample
-    if (DELTA) {  // cc:534-537
+    if (DELTA && !(FPV_ABL & 16)) {  // cc:534-537
       h.x = sub4(h.x, p.dh.x); h.y = sub4(h.y, p.dh.y);
       h.z = sub4(h.z, p.dh.z); h.w = sub4(h.w, p.dh.w);
       if (LOW) {
@@ -639,13 +623,15 @@ __device__ __forceinline__ void stream_step(StreamCtx& c, uint32_t it, const Pre
         l.z = sub4(l.z, p.dl.z); l.w = sub4(l.w, p.dl.w);
       }
     }
-    if (LOW) st_stream(c.low_f + c.s + o, l);
+    if (LOW && !(FPV_ABL & 32)) st_stream(c.low_f + c.s + o, l);
     const uint32_t a0 = ring_at(c, (int)o);
     *reinterpret_cast<uint4*>(c.ring + a0) = h;
     if (!c.use_cg) st_stream(c.high_f + c.s + o, h);
     __builtin_amdgcn_wave_barrier();  // the reads below see the whole wave's ring writes
     FPV_STAMP(3);  // delta + low store + ring write
-    if (c.use_cg) {  // cc:566-571
+    if ((FPV_ABL & 2) && c.use_cg && !(FPV_ABL & 64)) st_stream(c.high_f + c.s + o, h);
+    uint4 r = h;
+    if (c.use_cg && !(FPV_ABL & 2)) {  // cc:566-571
       uint32_t n0, c0;
       uint4 nv;
       c0 = *reinterpret_cast<const uint32_t*>(c.ring + ((a0 - 4) & c.ring_mask));
@@ -659,13 +645,7 @@ __device__ __forceinline__ void stream_step(StreamCtx& c, uint32_t it, const Pre
         nv.z = *reinterpret_cast<const uint32_t*>(c.ring + ((a0 - c.xs + 8) & c.ring_mask));
         nv.w = *reinterpret_cast<const uint32_t*>(c.ring + ((a0 - c.xs + 12) & c.ring_mask));
       }
-      uint32_t xo_prev = __builtin_amdgcn_perm(0, c0, 0x0c030c01u);
-      uint32_t no_prev = __builtin_amdgcn_perm(0, n0, 0x0c030c01u);
-      uint4 r;
-      r.x = cg_res4(h.x, nv.x, &xo_prev, &no_prev);
-      r.y = cg_res4(h.y, nv.y, &xo_prev, &no_prev);
-      r.z = cg_res4(h.z, nv.z, &xo_prev, &no_prev);
-      r.w = cg_res4(h.w, nv.w, &xo_prev, &no_prev);
+      r = (FPV_ABL & 1) ? make_uint4(h.x ^ nv.x, h.y ^ nv.y ^ c0, h.z ^ nv.z ^ n0, h.w ^ nv.w) : cg_res16(h, nv, c0, n0);
       // the first xs + 1 bytes of the plane are literals (cc:572): wave-uniform test first
       if (c.s == 0 && it * kStep < c.xs + 1) {
         const int nlit = (int)(c.xs + 1) - (int)o;  // literal pixels from the segment start
@@ -679,159 +659,357 @@ __device__ __forceinline__ void stream_step(StreamCtx& c, uint32_t it, const Pre
         }
         r = make_uint4(oo[0], oo[1], oo[2], oo[3]);
       }
-      st_stream(c.high_f + c.s + o, r);
+      if (!(FPV_ABL & 64)) st_stream(c.high_f + c.s + o, r);
     }
     FPV_STAMP(4);  // ring reads + clamped gradient + high store
-    {  // cc:554-562: the CG heuristic's sample at i = xs + 1 + 31 k, if one falls in this segment
-      const uint32_t j1 = c.q31 < 0 ? (uint32_t)(-c.q31) : (c.q31 ? 31u - (uint32_t)c.q31 : 0u);
-      if (j1 < 16) {
-        const uint32_t aj = a0 + j1;
+    if (!(FPV_ABL & 4)) {  // cc:554-562: the CG heuristic's sample at i = xs + 1 + 31 k, if one falls in this segment
+      // j1 = offset (0..30) of the next index congruent to xs + 1 (mod 31); a sample iff it lies
+      // inside the segment and not in front of xs + 1
+      const uint32_t pos = c.s + o + c.j1;
+      const uint32_t take = ((c.j1 - 16u) >> 31) & ((c.xs - pos) >> 31);  // j1 < 16 && pos > xs
+      if (c.use_cg) {
+        // with CG applied the sample's b = a - ClampedGradient(...) (cc:559-561) IS the
+        // residual just computed (samples start at xs + 1, behind the literal prefix)
+        const ByteSel bs = byte_sel(c.j1);
+        atomicAdd(&c.hist[256 + byte16(h, bs)], take);
+        atomicAdd(&c.hist[512 + byte16(r, bs)], take);
+      } else if (take) {
+        const uint32_t aj = a0 + c.j1;
         const int x = c.ring[aj & c.ring_mask], w = c.ring[(aj - 1) & c.ring_mask];
         const int n = c.ring[(aj - c.xs) & c.ring_mask], nw = c.ring[(aj - c.xs - 1) & c.ring_mask];
         hist_inc(c.hist, 1, (uint32_t)x);
         hist_inc(c.hist, 2, (uint32_t)(x - cg_pred(n, w, nw)) & 0xffu);
       }
-      if (c.q31 < 0) {
-        c.q31 += (int)kStep;
-        if (c.q31 >= 0) c.q31 %= 31;
-      } else {
-        c.q31 += (int)(kStep % 31u);
-        if (c.q31 >= 31) c.q31 -= 31;
-      }
+      const int t = (int)c.j1 - (int)(kStep % 31u);
+      c.j1 = (uint32_t)(t + ((t >> 31) & 31));
     }
     // advance this lane's (row, col) by one step
-    c.col += kStep % c.xs;
-    c.row += kStep / c.xs;
-    if (c.col >= c.xs) { c.col -= c.xs; c.row++; }
+    {
+      const int t = (int)(c.col + c.dcol) - (int)c.xs;   // dcol = kStep % xs, drow = kStep / xs
+      const int neg = t >> 31;
+      c.col = (uint32_t)(t + ((int)c.xs & neg));
+      c.row += c.drow + 1u + (uint32_t)neg;
+    }
   }
   __builtin_amdgcn_wave_barrier();
-  // preview groups completed by this step (wave-uniform)
-  const uint32_t end = min((it + 1) * kStep, c.npx);
-  stream_preview_flush(c, end / (4 * c.xs));
-  FPV_STAMP(5);  // CG sample + bookkeeping + preview flush
+  FPV_STAMP(5);  // CG sample + bookkeeping
 }
 
-// Kernel arguments kept small on purpose: everything else is derived.
-struct StreamArgs {
-  uint32_t xs, ys, npix, pw, npv;
-  uint32_t strip_rows, strips, ring_fwd, ring_base, nacc, shift, nframes, strip_major;
-};
-
+// One strip of one frame under the flags (DELTA, use_cg): everything of the pass
+// except the frame-level hand-off.  Returns with the strip's partial histograms
+// in c.hist and the OR of its raw low bytes in every lane.
 template <bool SWAP, bool FAST, bool DELTA, bool LOW>
-__global__ __launch_bounds__(64, 4) void k_stream(
-    const uint16_t* __restrict__ frames, const uint8_t* __restrict__ dhigh,
-    const uint8_t* __restrict__ dlow, const uint8_t* __restrict__ spec_ptr,
-    uint8_t* __restrict__ high, uint8_t* __restrict__ low, uint8_t* __restrict__ pv_raw,
-    uint32_t* __restrict__ anylow, uint16_t* __restrict__ partials,
-    uint32_t* __restrict__ counters, StreamArgs g) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  StreamCtx c;
-  c.lane = threadIdx.x;  // one wavefront per workgroup
+__device__ __forceinline__ uint32_t run_strip(StreamCtx& c, const StreamArgs& g, const StreamPtrs& P,
+                                              uint32_t frame, uint32_t strip, bool use_cg) {
+  const uint32_t row0 = strip * g.strip_rows;
+  const uint32_t rows = min(g.strip_rows, g.ys - row0);
+  const size_t fbase = (size_t)frame * g.npix;
+  c.use_delta = DELTA;
+  c.use_cg = use_cg;
+  c.s = row0 * g.xs;
+  c.npx = rows * g.xs;
+  c.img = P.frames + fbase;
+  c.dh = P.dhigh; c.dl = P.dlow;
+  c.high_f = P.high + fbase;
+  c.low_f = P.low + fbase;
+  c.pv_f = P.preview + (size_t)frame * g.npv;
+  c.rec = P.pvb + ((size_t)frame * g.strips + strip) * g.pvb_stride;
+  c.row = (c.lane * 16) / g.xs; c.col = (c.lane * 16) % g.xs;
+  c.j0 = (15u - (c.s + c.lane * 16) % 15u) % 15u;
+  {
+    const int d = ((int)(g.xs + 1) - (int)(c.s + c.lane * 16)) % 31;
+    c.j1 = (uint32_t)(d < 0 ? d + 31 : d);
+  }
+  c.or_low = 0;
+  c.groups_done = 0;
+  c.prow0 = row0 >> 2;
+  c.prows = rows >> 2;
+  c.first_strip = strip == 0;
+  c.last_strip = strip + 1 == g.strips;
+  c.wlast = c.wlast2 = 0;
+  const uint32_t niter = (c.npx + kStep - 1) / kStep;
+
+  for (uint32_t k = c.lane * 4; k < kHistFused * 256; k += 256)
+    *reinterpret_cast<uint4*>(c.hist + k) = make_uint4(0, 0, 0, 0);
+  if (c.s > 0) {  // halo: post-delta high bytes of the xs+16 pixels in front of the strip
+    const uint32_t hs = c.s - g.xs - 16, ngrp = (g.xs + 16) >> 2;
+    for (uint32_t k = c.lane; k < ngrp; k += 64) {
+      const uint2 v = *reinterpret_cast<const uint2*>(c.img + hs + 4 * k);
+      uint32_t h4, l4;
+      split4<SWAP>(v.x, v.y, (int)g.shift, &h4, &l4);
+      if (DELTA) h4 = sub4(h4, *reinterpret_cast<const uint32_t*>(P.dhigh + hs + 4 * k));
+      *reinterpret_cast<uint32_t*>(c.ring + ring_at(c, (int)(4 * k) - (int)(g.xs + 16))) = h4;
+    }
+    if (use_cg) {
+      // raw preview pixel (prow0 - 1, pw - 1): north-west of this strip's second preview
+      // row's first pixel.  Its 4x4 box lies in the four image rows above the strip.
+      uint32_t sum = 0;
+      if (c.lane < 4) {
+        const uint2 v = *reinterpret_cast<const uint2*>(c.img + (size_t)(row0 - 4 + c.lane) * g.xs + g.xs - 4);
+        uint32_t h4, l4;
+        split4<SWAP>(v.x, v.y, (int)g.shift, &h4, &l4);
+        sum = __builtin_amdgcn_sad_u8(h4, 0, 0);
+      }
+      sum += (uint32_t)__shfl_xor((int)sum, 1, 64);
+      sum += (uint32_t)__shfl_xor((int)sum, 2, 64);
+      c.wlast = ((uint32_t)__builtin_amdgcn_readfirstlane((int)sum) >> 4) & 0xfeu;
+    }
+  }
+  // kDepth steps of loads are in flight: the loads of step t + kDepth are issued when step t
+  // has consumed its registers.  The loop is unrolled by kDepth so that every stage keeps
+  // its own registers.
+  Pre p[kDepth];
+#pragma unroll
+  for (int d = 0; d < kDepth; d++) stream_load<FAST, DELTA, LOW>(c, d, niter, &p[d]);
+  __builtin_amdgcn_wave_barrier();
+
+  const uint32_t nd = niter - niter % kDepth;
+  for (uint32_t it = 0; it < nd; it += kDepth) {
+#pragma unroll
+    for (int d = 0; d < kDepth; d++) {
+      stream_step<SWAP, FAST, DELTA, LOW>(c, it + d, p[d]);
+      stream_load<FAST, DELTA, LOW>(c, it + d + kDepth, niter, &p[d]);
+    }
+    // preview rows completed by these steps (wave-uniform; the accumulator rows cover
+    // every 4-row group that kDepth steps can touch)
+    if (!(FPV_ABL & 8)) stream_preview_flush<FAST>(c, min((it + kDepth) * kStep, c.npx) / (4 * c.xs));
+  }
+#pragma unroll
+  for (int d = 0; d < kDepth - 1; d++)
+    if (nd + d < niter) stream_step<SWAP, FAST, DELTA, LOW>(c, nd + d, p[d]);
+  if (!(FPV_ABL & 8)) stream_preview_flush<FAST>(c, c.prows);
+
+  uint32_t orl = c.or_low;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) orl |= (uint32_t)__shfl_xor((int)orl, off, 64);
+  return orl;
+}
+
+// Sum over the 64 lanes of a wave; every lane gets the result.
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// EstimateEntropy (cc:235-244) of one 256-bin histogram held by a wave, four
+// bins per lane.  Exact integer arithmetic.
+__device__ __forceinline__ uint64_t entropy_wave(const uint32_t v[4]) {
+  const uint32_t sum = wave_sum(v[0] + v[1] + v[2] + v[3]);
+  if (sum == 0) return 0;
+  const uint32_t lsum = 31 - __clz(sum);
+  uint32_t term = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) term += v[k] ? v[k] * (lsum - (31 - __clz(v[k]))) : 0;
+  return (uint64_t)1024 * wave_sum(term) / sum;
+}
+
+// Clamped gradient of the preview rows that open a strip (cc:575-586): their north
+// row is the last row of the strip above, produced by another wave.  Both raw rows
+// come from the strips' boundary records.
+template <bool FAST>
+__device__ __forceinline__ void preview_boundary_rows(const StreamArgs& g, const uint8_t* pvb_frame,
+                                                      uint8_t* pv_f, uint32_t lane) {
+  const uint32_t prs = g.strip_rows >> 2;  // preview rows per strip
+  if (FAST) {
+    const uint32_t gpr = g.pw >> 4, items = (g.strips - 1) * gpr;
+    for (uint32_t it = lane; it < items; it += 64) {
+      const uint32_t s = 1 + it / gpr, k = (it % gpr) << 4;
+      const uint8_t* first = pvb_frame + (size_t)s * g.pvb_stride;
+      const uint8_t* last = pvb_frame + (size_t)(s - 1) * g.pvb_stride + g.pwr;
+      const uint4 cur = ld_agent128(first + k), north = ld_agent128(last + k);
+      const uint32_t wprev = k ? ld_agent32(first + k - 4) : ld_agent32(last + g.pw - 4);
+      const uint32_t nwprev = k ? ld_agent32(last + k - 4) : ld_agent32(last + g.pwr) << 24;
+      uint4 res = cg_res16(cur, north, wprev, nwprev);
+      if (s * prs == 1 && k == 0) res.x = (res.x & 0xffffff00u) | (cur.x & 0xffu);  // pixel pw is a literal (cc:575)
+      st_stream(pv_f + (size_t)s * prs * g.pw + k, res);
+    }
+  } else {
+    const uint32_t items = (g.strips - 1) * g.pw;
+    for (uint32_t it = lane; it < items; it += 64) {
+      const uint32_t s = 1 + it / g.pw, k = it % g.pw;
+      const uint8_t* first = pvb_frame + (size_t)s * g.pvb_stride;
+      const uint8_t* last = pvb_frame + (size_t)(s - 1) * g.pvb_stride + g.pwr;
+      const int x = (int)ld_agent8(first + k), n = (int)ld_agent8(last + k);
+      const int w = (int)(k ? ld_agent8(first + k - 1) : ld_agent8(last + g.pw - 1));
+      const int nw = (int)(k ? ld_agent8(last + k - 1) : ld_agent8(last + g.pwr));
+      const bool literal = s * prs == 1 && k == 0;  // pixel pw (cc:575 starts at pw + 1)
+      pv_f[(size_t)s * prs * g.pw + k] = (uint8_t)(literal ? x : (x - cg_pred(n, w, nw)) & 0xff);
+    }
+  }
+}
+
+// Strip epilogue: the strip's hand-off data leave through write-through stores, the
+// wave drains them, and ONE returning atomic both counts the strip as done and
+// fetches the wave's next task.  Returns true to the wave that completed the frame
+// (after an agent-scope acquire), *next_task = the task counter's old value.
+template <bool PARTIALS>
+__device__ __forceinline__ bool strip_arrive(const StreamCtx& c, const StreamArgs& g, const StreamPtrs& P,
+                                             uint32_t frame, uint32_t strip, uint32_t orl,
+                                             uint32_t* task_ctr, uint32_t* next_task) {
+  if (PARTIALS) {
+    uint8_t* ph = reinterpret_cast<uint8_t*>(P.partials + ((size_t)frame * g.strips + strip) * (kHistFused * 256));
+#pragma unroll
+    for (int i = 0; i < 3; i++) {  // 3 x 256 bins as 16-bit counts (a strip has at most 60000 samples): 192 x 8 bytes
+      const uint32_t idx = c.lane + 64 * i;
+      const uint4 v = *reinterpret_cast<const uint4*>(c.hist + 4 * idx);
+      st_agent64(ph + 8 * idx, (uint64_t)(v.x | (v.y << 16)) | ((uint64_t)(v.z | (v.w << 16)) << 32));
+    }
+  }
+  if (c.lane == 0 && orl) atomicOr(&P.anylow[frame], orl);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every store and atomic of this strip has left
+  uint32_t old = 0;
+  if (c.lane < (task_ctr ? 2u : 1u)) old = atomicAdd(c.lane == 0 ? &P.frame_done[frame] : task_ctr, 1u);
+  *next_task = (uint32_t)__builtin_amdgcn_readlane((int)old, 1);
+  const bool last = (uint32_t)__builtin_amdgcn_readlane((int)old, 0) + 1 == g.strips;
+  if (last) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (c.lane == 0) atomicExch(&P.frame_done[frame], 0u);  // ready for the redo pass / the next batch
+  }
+  return last;
+}
+
+// Flags byte (cc:447-449 + the decisions) and the strip-boundary preview rows.
+template <bool FAST>
+__device__ __forceinline__ void finalize_frame(const StreamCtx& c, const StreamArgs& g, const StreamPtrs& P,
+                                               uint32_t frame, uint32_t dec) {
+  if (c.lane == 0) P.flags[frame] = (uint8_t)(dec | (atomicExch(&P.anylow[frame], 0u) ? 0u : 4u));
+  if ((dec & 2u) && g.strips > 1)
+    preview_boundary_rows<FAST>(g, P.pvb + (size_t)frame * g.strips * g.pvb_stride,
+                                P.preview + (size_t)frame * g.npv, c.lane);
+}
+
+__device__ __forceinline__ void stream_ctx_init(StreamCtx& c, const StreamArgs& g, uint8_t* smem) {
+  c.lane = threadIdx.x & 63u;
   c.ring = smem;
   c.acc = reinterpret_cast<uint32_t*>(smem + g.ring_fwd);
   c.hist = reinterpret_cast<uint32_t*>(smem + g.ring_fwd + g.nacc * g.pw * 4);
+  c.pvprev = smem + g.ring_fwd + g.nacc * g.pw * 4 + kHistFused * 256 * 4;
   c.xs = g.xs; c.pw = g.pw; c.ring_mask = g.ring_fwd - 1; c.ring_base = g.ring_base;
-  c.nacc = g.nacc; c.shift = g.shift;
-  const uint32_t spec = *spec_ptr & (dhigh != nullptr ? 3u : 2u);
-  if (DELTA != (bool)(spec & 1)) return;  // the host launches both variants; the other one runs
-  c.use_delta = DELTA;
-  c.use_cg = spec & 2;
-  c.dh = dhigh; c.dl = dlow;
+  c.nacc = g.nacc; c.shift = g.shift; c.pwr = g.pwr;
+  c.drow = kStep / g.xs; c.dcol = kStep % g.xs;
+  for (uint32_t k = c.lane; k < g.nacc * g.pw; k += 64) c.acc[k] = 0;
+}
+
+// ---------------------------------------------------------------------------
+// k_stream: the fused speculative pass as a barrier-free streaming kernel.
+//
+// One WAVEFRONT owns one strip (strip_rows image rows) of one frame at a time
+// and pulls strips from a device-side counter.  Per step the wave handles 1024
+// consecutive pixels of the flattened plane, 16 per lane:
+//   - 32-byte coalesced pixel loads (and the delta bytes) come from a 3-deep
+//     register prefetch pipeline: the loads of step t+3 are issued when step t
+//     has consumed its registers, so each wave keeps ~6 KiB of HBM reads in
+//     flight and no load is waited for right after its issue;
+//   - the post-delta high bytes go into the wave's private LDS ring (the last
+//     xs+16+1024 bytes of the plane): the clamped gradient reads its north /
+//     north-west / west neighbours from there.  One wave executes its LDS
+//     operations in order, so no barrier is needed;
+//   - the 4x4 preview boxes are accumulated with LDS adds, one accumulator
+//     row per 4-row group; a finished row gets its clamped gradient (north =
+//     the previous raw row, kept in LDS) and is written at once;
+//   - the heuristic samples (i % 15 == 0; i = xs+1+31k) are counted in the
+//     wave's LDS histograms (16-bit bins packed in dwords).
+// ---------------------------------------------------------------------------
+// A workgroup is g.wg_waves wavefronts, each with its own LDS region and its own frame:
+// a task is one strip of wg_waves CONSECUTIVE frames, and the waves start it together, so
+// that the strip's delta bytes, which all of them read at about the same time, come from
+// the CU's L1 for all but the first.  Nothing else couples the waves of a workgroup.
+template <bool SWAP, bool FAST, bool LOW>
+__global__ __launch_bounds__(512, 2) void k_stream(StreamPtrs P, StreamArgs g) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const uint32_t W = g.wg_waves;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  uint32_t* next_slot = reinterpret_cast<uint32_t*>(smem + W * g.wave_lds);
+  StreamCtx c;
+  stream_ctx_init(c, g, smem + wave * g.wave_lds);
+  const uint32_t spec = *P.spec & (g.with_delta ? 3u : 2u);
+  const bool sp_delta = spec & 1u, sp_cg = spec & 2u;
+  if (blockIdx.x == 0 && threadIdx.x < kCtrWords) P.ctr_next[threadIdx.x] = 0;  // the next batch's counters
 #ifdef FPV_STAMPS
   for (int k = 0; k < 6; k++) c.seg[k] = 0;
   c.tlast = __builtin_amdgcn_s_memtime();
 #endif
-  for (uint32_t k = c.lane; k < g.nacc * g.pw; k += 64) c.acc[k] = 0;
-  const uint32_t row_l = (c.lane * 16) / g.xs, col_l = (c.lane * 16) % g.xs;
-
-  const uint32_t ntasks = g.nframes * g.strips;
-  // The first task of a wave is its workgroup index; only later ones come from the
-  // device-wide counter (2048 waves hitting one word at launch would queue for ~25 us:
+  const uint32_t ngroups = (g.nframes + W - 1) / W;
+  const uint32_t ntasks = ngroups * g.strips;
+  // The first task of a workgroup is its index; later ones come from the device-wide
+  // counter (thousands of waves hitting one word at launch would queue for ~25 us:
   // same-address atomics serialise at ~12 ns).
-  bool first = true;
-  for (;;) {
-    uint32_t task = blockIdx.x;
-    if (!first) {
-      if (c.lane == 0) task = gridDim.x + atomicAdd(&counters[6], 1u);
-      task = __builtin_amdgcn_readfirstlane(task);
-    }
-    first = false;
-    if (task >= ntasks) {
-#ifdef FPV_STAMPS
-      if (c.lane == 0)  // stamps leave through a buffer nothing else reads (counters[16..27])
-        for (int k = 0; k < 6; k++)
-          atomicAdd(reinterpret_cast<unsigned long long*>(counters + 16) + k, c.seg[k]);
-#endif
-      break;
-    }
+  uint32_t task = blockIdx.x;
+  while (task < ntasks) {
     // Strip-major order: waves resident at the same time work on the SAME strip of
     // different frames, so the strip's delta bytes are shared through L1/L2.
-    uint32_t frame, strip;
+    uint32_t group, strip;
     if (g.strip_major) {
-      strip = task / g.nframes;
-      frame = task - strip * g.nframes;
+      strip = task / ngroups;
+      group = task - strip * ngroups;
     } else {
-      frame = task / g.strips;
-      strip = task - frame * g.strips;
+      group = task / g.strips;
+      strip = task - group * g.strips;
     }
-    const uint32_t row0 = strip * g.strip_rows;
-    const uint32_t rows = min(g.strip_rows, g.ys - row0);
-    const size_t fbase = (size_t)frame * g.npix;
-    c.s = row0 * g.xs;
-    c.npx = rows * g.xs;
-    c.img = frames + fbase;
-    c.high_f = high + fbase;
-    c.low_f = low + fbase;
-    c.pv_f = pv_raw + (size_t)frame * g.npv;
-    c.row = row_l; c.col = col_l;
-    c.m15 = (c.s + c.lane * 16) % 15u;
-    c.q31 = (int)(c.s + c.lane * 16) - (int)(g.xs + 1);
-    if (c.q31 >= 0) c.q31 %= 31;
-    c.or_low = 0;
-    c.groups_done = 0;
-    c.prow0 = row0 >> 2;
-    const uint32_t niter = (c.npx + kStep - 1) / kStep;
-
-    for (uint32_t k = c.lane * 4; k < kHistFused * 128; k += 256)
-      *reinterpret_cast<uint4*>(c.hist + k) = make_uint4(0, 0, 0, 0);
-    if (c.s > 0) {  // halo: post-delta high bytes of the xs+16 pixels in front of the strip
-      const uint32_t hs = c.s - g.xs - 16, ngrp = (g.xs + 16) >> 2;
-      for (uint32_t k = c.lane; k < ngrp; k += 64) {
-        const uint2 v = *reinterpret_cast<const uint2*>(c.img + hs + 4 * k);
-        uint32_t h4, l4;
-        split4<SWAP>(v.x, v.y, (int)g.shift, &h4, &l4);
-        if (c.use_delta) h4 = sub4(h4, *reinterpret_cast<const uint32_t*>(dhigh + hs + 4 * k));
-        *reinterpret_cast<uint32_t*>(c.ring + ring_at(c, (int)(4 * k) - (int)(g.xs + 16))) = h4;
+    const uint32_t frame = group * W + wave;
+    uint32_t next = 0;
+    if (frame < g.nframes) {
+    const uint32_t orl = sp_delta ? run_strip<SWAP, FAST, true, LOW>(c, g, P, frame, strip, sp_cg)
+                                  : run_strip<SWAP, FAST, false, LOW>(c, g, P, frame, strip, sp_cg);
+    const bool last = strip_arrive<true>(c, g, P, frame, strip, orl, wave == 0 ? &P.ctr[kCtrTask] : nullptr, &next);
+    if (last) {
+      // EstimateEntropy + the two decisions (cc:533, cc:564) from the strips' histograms
+      const uint8_t* ph = reinterpret_cast<const uint8_t*>(P.partials + (size_t)frame * g.strips * (kHistFused * 256)) + c.lane * 8;
+      uint32_t v[kHistFused][4] = {};
+      for (uint32_t t = 0; t < g.strips; t++) {
+#pragma unroll
+        for (int h = 0; h < kHistFused; h++) {
+          const uint64_t q = ld_agent64(ph + (size_t)(t * kHistFused + h) * 512);  // 4 x u16
+          v[h][0] += (uint32_t)q & 0xffffu; v[h][1] += ((uint32_t)q) >> 16;
+          v[h][2] += (uint32_t)(q >> 32) & 0xffffu; v[h][3] += (uint32_t)(q >> 48);
+        }
+      }
+      // cc:533: E(countd) < E(counta); countd has everything in bin 0, E(countd) == 0
+      const bool use_delta = g.with_delta && entropy_wave(v[0]) > 0;
+      if (use_delta != sp_delta) {  // the CG histograms were taken under the wrong delta decision
+        if (c.lane == 0) {
+          P.decision[frame] = 0xff;
+          P.list_a[atomicAdd(&P.ctr[kCtrListA], 1u)] = frame;
+        }
+      } else {
+        const uint64_t ea = entropy_wave(v[1]);
+        const uint64_t eb = entropy_wave(v[2]);
+        const bool use_cg = eb < ea;  // cc:564
+        const uint32_t dec = (use_delta ? 1u : 0u) | (use_cg ? 2u : 0u);
+        if (c.lane == 0) {
+          P.decision[frame] = (uint8_t)dec;
+          atomicAdd(&P.ctr[kCtrVotes + dec], 1u);
+          if (use_cg != sp_cg) P.list_b[atomicAdd(&P.ctr[kCtrListB], 1u)] = frame;
+        }
+        if (use_cg == sp_cg) finalize_frame<FAST>(c, g, P, frame, dec);
       }
     }
-    Pre p0, p1, p2;
-    stream_load<FAST, DELTA, LOW>(c, 0, niter, &p0);
-    stream_load<FAST, DELTA, LOW>(c, 1, niter, &p1);
-    stream_load<FAST, DELTA, LOW>(c, 2, niter, &p2);
-    __builtin_amdgcn_wave_barrier();
-
-    const uint32_t n3 = niter - niter % 3;
-    for (uint32_t it = 0; it < n3; it += 3) {
-      stream_step<SWAP, FAST, DELTA, LOW>(c, it, p0);
-      stream_load<FAST, DELTA, LOW>(c, it + 3, niter, &p0);
-      stream_step<SWAP, FAST, DELTA, LOW>(c, it + 1, p1);
-      stream_load<FAST, DELTA, LOW>(c, it + 4, niter, &p1);
-      stream_step<SWAP, FAST, DELTA, LOW>(c, it + 2, p2);
-      stream_load<FAST, DELTA, LOW>(c, it + 5, niter, &p2);
     }
-    if (n3 < niter) stream_step<SWAP, FAST, DELTA, LOW>(c, n3, p0);
-    if (n3 + 1 < niter) stream_step<SWAP, FAST, DELTA, LOW>(c, n3 + 1, p1);
-
-    // strip epilogue: NO_LOW accumulator and the partial histograms
-    uint32_t orl = c.or_low;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) orl |= __shfl_xor(orl, off, 64);
-    if (c.lane == 0 && orl) atomicOr(&anylow[frame], orl);
-    uint32_t* ph = reinterpret_cast<uint32_t*>(partials + ((size_t)frame * g.strips + strip) * (kHistFused * 256));
-    for (uint32_t k = c.lane * 4; k < kHistFused * 128; k += 256)
-      *reinterpret_cast<uint4*>(ph + k) = *reinterpret_cast<const uint4*>(c.hist + k);
+    if (W > 1) {  // wave 0 (always active) fetched the workgroup's next task
+      if (threadIdx.x == 0) *next_slot = next;
+      __syncthreads();
+      next = *reinterpret_cast<volatile uint32_t*>(next_slot);
+      __syncthreads();
+    }
+    task = gridDim.x + next;
     __builtin_amdgcn_wave_barrier();
   }
+#ifdef FPV_STAMPS
+  if (c.lane == 0)  // stamps leave through a buffer nothing else reads (ctr_next[32..43])
+    for (int k = 0; k < 6; k++)
+      atomicAdd(reinterpret_cast<unsigned long long*>(P.ctr_next + 32) + k, c.seg[k]);
+#endif
+}
+
+// Sum over the 256 threads of a block; every thread gets the result.
+__device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t* scratch) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  __syncthreads();  // scratch may still be read from a previous call
+  if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return scratch[0] + scratch[1] + scratch[2] + scratch[3];
 }
 
 // EstimateEntropy (cc:235-244) of one 256-bin histogram, one bin per thread.
@@ -844,81 +1022,22 @@ __device__ __forceinline__ uint64_t entropy_bins(uint32_t v, uint32_t* scratch) 
   return (uint64_t)1024 * s / sum;
 }
 
-// Sum over the 64 lanes of a wave; every lane gets the result.
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
+// ---- exact redo of mis-speculated frames (list driven) ----
 
-// EstimateEntropy (cc:235-244) of one 256-bin histogram held by a wave, four
-// bins per lane.  Same integer arithmetic as entropy_bins.
-__device__ __forceinline__ uint64_t entropy_wave(const uint32_t v[4]) {
-  const uint32_t sum = wave_sum(v[0] + v[1] + v[2] + v[3]);
-  if (sum == 0) return 0;
-  const uint32_t lsum = 31 - __clz(sum);
-  uint32_t term = 0;
-#pragma unroll
-  for (int k = 0; k < 4; k++) term += v[k] ? v[k] * (lsum - (31 - __clz(v[k]))) : 0;
-  return (uint64_t)1024 * wave_sum(term) / sum;
-}
-
-// Workspace counters (u32): [0] |list A|, [1] |list B|, [6] k_stream's task counter.
-// One WAVE per frame (four frames per workgroup): no barriers, the reductions are
-// wave shuffles, so all frames of a batch decide concurrently.
-__global__ __launch_bounds__(kThreads) void k_decide_spec(
-    const uint16_t* __restrict__ partials, const uint8_t* __restrict__ spec_ptr,
-    uint8_t* __restrict__ decision, uint32_t* __restrict__ counters,
-    uint32_t* __restrict__ list_a, uint32_t* __restrict__ list_b, Geom g, int with_delta,
-    uint32_t nframes) {
-  const uint32_t frame = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (frame >= nframes) return;
-  const uint32_t nparts = g.strips;
-  const uint16_t* ph = partials + (size_t)frame * nparts * (kHistFused * 256) + lane * 4;
-  uint32_t v[kHistFused][4] = {};
-#pragma unroll 4
-  for (uint32_t t = 0; t < nparts; t++) {
-#pragma unroll
-    for (int h = 0; h < kHistFused; h++) {
-      const uint2 q = *reinterpret_cast<const uint2*>(ph + (t * kHistFused + h) * 256);  // 4 x u16
-      v[h][0] += q.x & 0xffffu; v[h][1] += q.x >> 16;
-      v[h][2] += q.y & 0xffffu; v[h][3] += q.y >> 16;
-    }
-  }
-  const uint32_t spec = *spec_ptr & (with_delta ? 3u : 2u);
-  // cc:533: E(countd) < E(counta); countd has everything in bin 0, E(countd) == 0
-  const bool use_delta = with_delta && entropy_wave(v[0]) > 0;
-  if (use_delta != (bool)(spec & 1)) {
-    if (lane == 0) {
-      decision[frame] = 0xff;
-      list_a[atomicAdd(&counters[0], 1u)] = frame;
-    }
-    return;
-  }
-  const uint64_t ea = entropy_wave(v[1]);
-  const uint64_t eb = entropy_wave(v[2]);
-  const bool use_cg = eb < ea;  // cc:564
-  if (lane == 0) {
-    const uint32_t dec = (use_delta ? 1u : 0u) | (use_cg ? 2u : 0u);
-    decision[frame] = (uint8_t)dec;
-    if (use_cg != (bool)(spec & 2)) list_b[atomicAdd(&counters[1], 1u)] = frame;
-  }
-}
-
-// ---- exact fallback for mis-speculated frames (list driven, grid stride) ----
+constexpr int kListGrid = 256;  // workgroups of k_redo_decide
 
 // Exact decisions of the frames whose delta decision was mis-speculated (list A;
 // normally empty, the launch exits at once): one workgroup per listed frame takes
 // all five histograms (both delta hypotheses) of the heuristics' samples in LDS,
-// evaluates EstimateEntropy and appends the frame to list B for the re-apply pass.
+// evaluates EstimateEntropy and appends the frame to list B for the redo pass.
 template <bool SWAP>
 __global__ __launch_bounds__(kThreads) void k_redo_decide(
     const uint16_t* __restrict__ frames, const uint8_t* __restrict__ dhigh,
-    uint8_t* __restrict__ decision, uint32_t* __restrict__ counters,
+    uint8_t* __restrict__ decision, uint32_t* __restrict__ ctr,
     const uint32_t* __restrict__ list_a, uint32_t* __restrict__ list_b, Geom g, int with_delta) {
   __shared__ uint32_t lh[kNumHists * 256];
   __shared__ uint32_t scratch[4];
-  const uint32_t na = counters[0];
+  const uint32_t na = ctr[kCtrListA];
   for (uint32_t w = blockIdx.x; w < na; w += gridDim.x) {
     const uint32_t frame = list_a[w];
     const uint16_t* img = frames + (size_t)frame * g.npix;
@@ -956,137 +1075,48 @@ __global__ __launch_bounds__(kThreads) void k_redo_decide(
     const uint64_t eb = entropy_bins(ha[256 + threadIdx.x], scratch);
     const bool use_cg = eb < ea;
     if (threadIdx.x == 0) {
-      decision[frame] = (uint8_t)((use_delta ? 1u : 0u) | (use_cg ? 2u : 0u));
-      list_b[atomicAdd(&counters[1], 1u)] = frame;
+      const uint32_t dec = (use_delta ? 1u : 0u) | (use_cg ? 2u : 0u);
+      decision[frame] = (uint8_t)dec;
+      atomicAdd(&ctr[kCtrVotes + dec], 1u);
+      list_b[atomicAdd(&ctr[kCtrListB], 1u)] = frame;
     }
     __syncthreads();
   }
 }
 
-// Non-speculative tile pass under the frame's TRUE flags.
-template <bool SWAP>
-__global__ __launch_bounds__(kThreads) void k_apply_list(
-    const uint16_t* __restrict__ frames, const uint8_t* __restrict__ dhigh,
-    const uint8_t* __restrict__ dlow, const uint8_t* __restrict__ decision,
-    const uint32_t* __restrict__ counters, const uint32_t* __restrict__ list_b,
-    uint8_t* __restrict__ high, uint8_t* __restrict__ low, uint8_t* __restrict__ pv_raw,
-    uint32_t* __restrict__ anylow, Geom g) {
+// The strip pass of k_stream under each listed frame's TRUE flags, and the next
+// batch's speculation: the most frequent decision of this batch (all votes are
+// in: they are cast by k_stream and k_redo_decide).
+template <bool SWAP, bool FAST, bool LOW>
+__global__ __launch_bounds__(64, 2) void k_redo_stream(StreamPtrs P, StreamArgs g) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const TileLds L = tile_lds(smem, g);
-  const uint32_t tid = threadIdx.x, items = counters[1] * g.tiles;
-  const uint4 zero = make_uint4(0, 0, 0, 0);
-  for (uint32_t w = blockIdx.x; w < items; w += gridDim.x) {
-    const uint32_t frame = list_b[w / g.tiles];
-    const TileCtx t = tile_ctx(g, w % g.tiles);
-    const size_t fbase = (size_t)frame * g.npix;
-    const uint16_t* img = frames + fbase;
-    const uint32_t dec = decision[frame];
-    const bool use_delta = dec & 1, use_cg = dec & 2;
-    if (tid == 0) *L.s_or = 0;
-    if (t.s > 0 && use_cg) load_halo<SWAP>(g, t, L, img, dhigh, use_delta);
-    __syncthreads();
-    uint32_t or_low = 0;
-    for (uint32_t seg = tid; seg < t.nseg; seg += kThreads) {
-      const uint32_t o = seg << 4;
-      const uint4 pa = *reinterpret_cast<const uint4*>(img + t.s + o);
-      const uint4 pb = *reinterpret_cast<const uint4*>(img + t.s + o + 8);
-      uint4 dh = zero, dl = zero;
-      if (use_delta) {
-        dh = *reinterpret_cast<const uint4*>(dhigh + t.s + o);
-        if (g.shift != 8) dl = *reinterpret_cast<const uint4*>(dlow + t.s + o);
-      }
-      seg_phase_a<SWAP, false>(g, t, L, o, pa, pb, dh, dl, use_delta, use_cg, high + fbase,
-                               low + fbase, &or_low);
-    }
-    tile_or_low(L, or_low);
-    __syncthreads();
-    for (uint32_t seg = tid; seg < t.nseg; seg += kThreads)
-      seg_phase_b<false>(g, t, L, seg << 4, use_cg, high + fbase);
-    tile_preview(g, t, L, pv_raw + (size_t)frame * g.npv);
-    if (tid == 0 && *L.s_or) atomicOr(&anylow[frame], *L.s_or);
-    __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    uint32_t best = 0, nbest = P.ctr[kCtrVotes];
+    for (uint32_t k = 1; k < 4; k++)
+      if (P.ctr[kCtrVotes + k] > nbest) { best = k; nbest = P.ctr[kCtrVotes + k]; }
+    if (nbest) *P.spec = (uint8_t)best;
   }
-}
-
-// Preview clamped gradient (cc:575-586), final flags byte (cc:447-449) and the
-// speculation for the next batch (majority of this batch's decisions).
-// WIDE: pw % 16 == 0 -> 16 preview pixels per thread with the packed median.
-template <bool WIDE>
-__global__ __launch_bounds__(kThreads) void k_finish(
-    const uint8_t* __restrict__ pv_raw, const uint8_t* __restrict__ decision,
-    const uint32_t* __restrict__ anylow, const uint32_t* __restrict__ counters,
-    uint8_t* __restrict__ preview, uint8_t* __restrict__ flags, uint8_t* __restrict__ spec_ptr,
-    Geom g) {
-  const uint32_t frame = blockIdx.y;
-  const uint32_t dec = decision[frame];
-  const uint8_t* in = pv_raw + (size_t)frame * g.npv;
-  uint8_t* out = preview + (size_t)frame * g.npv;
-  constexpr uint32_t kPer = WIDE ? 16 : 4;
-  const uint32_t i = (blockIdx.x * kThreads + threadIdx.x) * kPer;
-  if (i < g.npv) {
-    if (WIDE) {
-      const uint4 c4 = *reinterpret_cast<const uint4*>(in + i);
-      uint4 r4 = c4;
-      if ((dec & 2) && i >= g.pw) {  // rows >= 1; row 0 and pixel pw are literals
-        const uint4 n4 = *reinterpret_cast<const uint4*>(in + i - g.pw);
-        // west / north-west of the first pixel: the dwords in front of the two segments
-        uint32_t xo_prev = __builtin_amdgcn_perm(0, *reinterpret_cast<const uint32_t*>(in + i - 4), 0x0c030c01u);
-        uint32_t no_prev = i > g.pw ? __builtin_amdgcn_perm(0, *reinterpret_cast<const uint32_t*>(in + i - g.pw - 4), 0x0c030c01u) : 0u;
-        r4.x = cg_res4(c4.x, n4.x, &xo_prev, &no_prev);
-        r4.y = cg_res4(c4.y, n4.y, &xo_prev, &no_prev);
-        r4.z = cg_res4(c4.z, n4.z, &xo_prev, &no_prev);
-        r4.w = cg_res4(c4.w, n4.w, &xo_prev, &no_prev);
-        if (i == g.pw) r4.x = (r4.x & 0xffffff00u) | (c4.x & 0xffu);  // pixel pw itself is a literal
-      }
-      *reinterpret_cast<uint4*>(out + i) = r4;
-    } else if ((g.pw & 3) == 0) {  // npv and pw multiples of 4: dword path
-      const uint32_t c4 = *reinterpret_cast<const uint32_t*>(in + i);
-      uint32_t r4 = c4;
-      if ((dec & 2) && i + 3 >= g.pw + 1) {
-        const uint32_t n4 = *reinterpret_cast<const uint32_t*>(in + i - g.pw);
-        int w = in[i - 1], nw = i > g.pw ? in[i - g.pw - 1] : 0;  // pixel pw is a literal
-        r4 = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const int x = (int)byte_of(c4, j), n = (int)byte_of(n4, j);
-          int res = (x - cg_pred(n, w, nw)) & 0xff;
-          if (i + j < g.pw + 1) res = x;
-          r4 |= (uint32_t)res << (8 * j);
-          w = x;
-          nw = n;
-        }
-      }
-      *reinterpret_cast<uint32_t*>(out + i) = r4;
-    } else {
-      for (uint32_t k = i; k < min(i + 4, g.npv); k++) {
-        int x = in[k];
-        if ((dec & 2) && k >= g.pw + 1)
-          x = (x - cg_pred(in[k - g.pw], in[k - 1], in[k - g.pw - 1])) & 0xff;
-        out[k] = (uint8_t)x;
-      }
-    }
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) flags[frame] = (uint8_t)(dec | (anylow[frame] ? 0 : 4));
-  if (blockIdx.x == 0 && frame == 0) {
-    // Next batch's speculation = the most frequent decision of this one.  All
-    // decisions are final here (stream order).  Counted by this one workgroup from
-    // the decision bytes: a thousand frames voting with global atomics on one word
-    // cost the decision kernel ~12 us (same-address atomics serialise at ~12 ns).
-    __shared__ uint32_t votes[4];
-    if (threadIdx.x < 4) votes[threadIdx.x] = 0;
-    __syncthreads();
-    uint32_t mine[4] = {0, 0, 0, 0};
-    for (uint32_t f = threadIdx.x; f < gridDim.y; f += kThreads) mine[decision[f] & 3u]++;
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-      if (mine[k]) atomicAdd(&votes[k], mine[k]);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      uint32_t best = 0;
-      for (uint32_t k = 1; k < 4; k++)
-        if (votes[k] > votes[best]) best = k;
-      *spec_ptr = (uint8_t)best;
-    }
+  const uint32_t nb = P.ctr[kCtrListB];
+  if (nb == 0) return;
+  StreamCtx c;
+  stream_ctx_init(c, g, smem);
+#ifdef FPV_STAMPS
+  for (int k = 0; k < 6; k++) c.seg[k] = 0;
+  c.tlast = __builtin_amdgcn_s_memtime();
+#endif
+  const uint32_t ntasks = nb * g.strips;
+  uint32_t task = blockIdx.x;
+  while (task < ntasks) {
+    const uint32_t strip = task / nb;
+    const uint32_t frame = P.list_b[task - strip * nb];
+    const uint32_t dec = P.decision[frame];
+    const uint32_t orl = (dec & 1u) ? run_strip<SWAP, FAST, true, LOW>(c, g, P, frame, strip, dec & 2u)
+                                    : run_strip<SWAP, FAST, false, LOW>(c, g, P, frame, strip, dec & 2u);
+    uint32_t next;
+    const bool last = strip_arrive<false>(c, g, P, frame, strip, orl, &P.ctr[kCtrRedoTask], &next);
+    task = gridDim.x + next;
+    if (last) finalize_frame<FAST>(c, g, P, frame, dec);
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -2031,42 +2061,37 @@ static void spec_geom(Geom* g) {
   g->spec_ring = r;
 }
 
+// Per-device multiprocessor count (the persistent grids are sized by it).
+static uint32_t device_cus() {
+  static std::mutex m;
+  static int cus[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  dev &= 63;
+  std::lock_guard<std::mutex> l(m);
+  if (!cus[dev]) {
+    hipDeviceProp_t prop;
+    int n = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 0;
+    cus[dev] = n > 0 ? n : 256;
+  }
+  return (uint32_t)cus[dev];
+}
+
+constexpr uint32_t kMaxWaveLds = 160 * 1024 - 1024;  // one wave may own (nearly) the whole LDS of a CU
+
 bool make_geom(uint32_t xs, uint32_t ys, int shift, int big_endian, Geom* g,
                const char** why) {
   static const char* kDims = "xsize and ysize must be non-zero multiples of 4";
   static const char* kShift = "shift must be 0..8 (0..15 for little-endian input)";
-  static const char* kWide = "xsize too large for the LDS line buffer";
+  static const char* kWide = "xsize too large for the LDS line buffer of the forward kernel (about 32K pixels)";
   static const char* kBig = "frame larger than 2^31 pixels";
   if (!xs || !ys || (xs & 3) || (ys & 3)) { *why = kDims; return false; }
   if (shift < 0 || shift > 15 || (big_endian && shift > 8)) { *why = kShift; return false; }
   if ((uint64_t)xs * ys >= (1ull << 31)) { *why = kBig; return false; }
+  *g = Geom();
   g->xs = xs; g->ys = ys; g->npix = xs * ys;
   g->pw = xs / 4; g->ph = ys / 4; g->npv = g->pw * g->ph;
   g->shift = shift; g->swap = big_endian ? 1 : 0;
-  // Forward tile: whole preview rows (multiples of 4 image rows), at most
-  // kMaxIter 16-pixel segments per thread, and as few idle threads in the last
-  // pass over the tile as possible (nseg close to a multiple of 256).
-  uint32_t rows = 4;
-  {
-    const uint32_t max_px = kMaxIter * kThreads * 16;
-    double best = -1.0;
-    for (uint32_t r = 4; r <= ys && (uint64_t)r * xs <= max_px; r += 4) {
-      const uint32_t nseg = r * xs / 16, passes = (nseg + kThreads - 1) / kThreads;
-      const double eff = (double)nseg / (passes * kThreads) + 1e-4 * r;  // ties: larger tile
-      if (eff > best) { best = eff; rows = r; }
-    }
-  }
-  if (const char* e = getenv("FPV_TILE_ROWS")) rows = std::max(4u, (uint32_t)atoi(e) & ~3u);
-  if (rows > ys) rows = ys;
-  g->tile_rows = rows;
-  g->tile_px = rows * xs;
-  g->tiles = (ys + rows - 1) / rows;
-  if (g->tile_px > kMaxIter * kThreads * 16) { *why = kWide; return false; }
-  g->lds_off = round_up(xs + 16, 16);
-  g->lds_h_bytes = round_up(g->lds_off + g->tile_px, 16);
-  g->lds_hist_off = round_up(g->lds_h_bytes + g->tile_px / 2, 16);
-  g->lds_bytes = g->lds_hist_off + kHistFused * 256 * 4 + 16;
-  if (g->lds_bytes > 160 * 1024 - 64) { *why = kWide; return false; }
   // streaming kernel: strips of about 100K pixels (whole preview rows), one wave each
   {
     // Prefer a strip height that divides ys and whose pixel count is a multiple
@@ -2088,24 +2113,48 @@ bool make_geom(uint32_t xs, uint32_t ys, int shift, int big_endian, Geom* g,
     if (const char* e = getenv("FPV_STRIP_ROWS")) srows = std::max(4u, (uint32_t)atoi(e) & ~3u);
     if (srows > ys) srows = ys;
     while ((uint64_t)srows * xs > 15u * 60000u && srows > 4) srows -= 4;  // 16-bit histogram bins
+    if ((uint64_t)srows * xs > 15u * 65000u) { *why = kWide; return false; }
     g->strip_rows = srows;
     g->strips = (ys + srows - 1) / srows;
     g->ring_base = round_up(xs + 16, 16);
     uint32_t rf = 1;
     while (rf < g->ring_base + kStep) rf <<= 1;
     g->ring_fwd = rf;
-    g->nacc = (kStep + 4 * xs - 1) / (4 * xs) + 1;
-    g->wave_lds = round_up(rf + g->nacc * g->pw * 4 + kHistFused * 128 * 4, 16);
-    if (g->wave_lds > 64 * 1024) { *why = kWide; return false; }
+    // preview accumulator rows: every 4-row group that kDepth steps (one flush interval) can touch
+    g->nacc = (kDepth * kStep + 4 * xs - 1) / (4 * xs) + 1;
+    const bool fast_shape = (xs & 63) == 0 && xs >= 256;
+    if (fast_shape) g->nacc = g->nacc <= 2 ? 2 : g->nacc <= 4 ? 4 : 8;  // FAST indexes them with a mask
+    g->pwr = round_up(g->pw, 16);
+    g->pvb_stride = 2 * g->pwr + 16;
+    // ring | preview accumulators | histograms | previous raw preview row
+    g->wave_lds = round_up(rf + g->nacc * g->pw * 4 + kHistFused * 256 * 4 + g->pwr, 16);
+    if (g->wave_lds > kMaxWaveLds) { *why = kWide; return false; }
     uint32_t wpc = (160 * 1024 - 1024) / g->wave_lds;
     g->stream_waves_per_cu = std::max(1u, std::min(8u, wpc));  // measured: 8 beats 12 beats 16 (memory-system contention)
-    if (const char* e = getenv("FPV_WAVES_PER_CU")) g->stream_waves_per_cu = std::max(1, atoi(e));
+    if (const char* e = getenv("FPV_WAVES_PER_CU")) g->stream_waves_per_cu = std::max(1u, std::min(wpc, (uint32_t)atoi(e)));
+    // waves per workgroup: a power of two that divides the waves per CU
+    g->wg_waves = 1;
+    if (const char* e = getenv("FPV_WG_WAVES")) {
+      const uint32_t want = (uint32_t)atoi(e);
+      for (uint32_t w = 1; w <= 8 && w <= want; w <<= 1)
+        if (g->stream_waves_per_cu % w == 0) g->wg_waves = w;
+    }
+    // FAST: every step of every strip is full, a 16-pixel segment never straddles image
+    // rows, a preview row is a whole number of 16-byte groups
+    g->fast = fast_shape && ((uint64_t)g->strip_rows * xs) % kStep == 0 && ys % g->strip_rows == 0;
+    // The redo pass of mis-speculated frames cuts a frame into short strips (about 8K
+    // pixels): usually only a few frames are listed, and a strip is a serial task.
+    g->redo_strip_rows = g->strip_rows;
+    for (uint32_t r = 4; r < g->strip_rows; r += 4) {
+      if ((uint64_t)r * xs < 8192) continue;
+      if (g->fast && (ys % r || ((uint64_t)r * xs) % kStep)) continue;
+      g->redo_strip_rows = r;
+      break;
+    }
+    g->redo_strips = (ys + g->redo_strip_rows - 1) / g->redo_strip_rows;
   }
   g->nd = (g->npix + 14) / 15;
   g->ncg = g->npix > xs + 1 ? (g->npix - xs - 1 + 30) / 31 : 0;
-  uint32_t samples = g->nd + g->ncg;
-  g->stat_blocks = (samples + kThreads * 8 - 1) / (kThreads * 8);
-  if (g->stat_blocks < 1) g->stat_blocks = 1;
   uint32_t ring = 1;
   while (ring < xs + 1 + kInvChunk + 4) ring <<= 1;
   g->ring = ring;
@@ -2134,39 +2183,46 @@ bool make_geom_decoder(uint32_t xs, uint32_t ys, Geom* g, const char** why) {
   return true;
 }
 
-// Workspace layout: [counters | anylow] are zeroed by ONE memset per batch; the
-// rest is fully written by the kernels.  `spec` survives batches.
+// Workspace layout: [counter blocks | anylow | frame_done] are cleared ONCE when the
+// workspace is created; afterwards the kernels leave them clean (the counter blocks
+// alternate between batches, the wave that finalises a frame resets its two words).
+// The rest is fully written by the kernels.  `spec` survives batches.
 size_t fwd_workspace_bytes(const Geom& g, uint32_t max_frames) {
-  size_t b = 256 + round_up(max_frames * 4, 256);                // counters, anylow
+  size_t b = 512 + 2 * (size_t)round_up(max_frames * 4, 256);    // counter blocks, anylow, frame_done
   b += round_up(max_frames, 256);                                // decision
   b += 2 * (size_t)round_up(max_frames * 4, 256);                // list A, list B
-  b += round_up((size_t)max_frames * g.npv, 256);                // pv_raw
-  b += (size_t)max_frames * g.strips * kHistFused * 256 * 2;  // partial histograms (u16)
+  b += round_up((size_t)max_frames * g.redo_strips * g.pvb_stride, 256);  // boundary preview rows (redo_strips >= strips)
+  b += (size_t)max_frames * g.strips * kHistFused * 256 * 2;     // partial histograms (u16)
   return b + 256 /* spec */ + 256;
 }
 
 void carve_fwd_workspace(const Geom& g, uint32_t max_frames, void* base,
                          FwdWorkspace* ws) {
   uint8_t* p = static_cast<uint8_t*>(base);
-  ws->counters = reinterpret_cast<uint32_t*>(p);
-  p += 256;
+  ws->ctr = reinterpret_cast<uint32_t*>(p);
+  p += 512;
   ws->anylow = reinterpret_cast<uint32_t*>(p);
   p += round_up(max_frames * 4, 256);
-  ws->zero_fixed = (size_t)(p - static_cast<uint8_t*>(base));
+  ws->frame_done = reinterpret_cast<uint32_t*>(p);
+  p += round_up(max_frames * 4, 256);
+  ws->zero_bytes = (size_t)(p - static_cast<uint8_t*>(base));
   ws->decision = p;
   p += round_up(max_frames, 256);
   ws->list_a = reinterpret_cast<uint32_t*>(p);
   p += round_up(max_frames * 4, 256);
   ws->list_b = reinterpret_cast<uint32_t*>(p);
   p += round_up(max_frames * 4, 256);
-  ws->pv_raw = p;
-  p += round_up((size_t)max_frames * g.npv, 256);
+  ws->pvb = p;
+  p += round_up((size_t)max_frames * g.redo_strips * g.pvb_stride, 256);
   ws->partials = reinterpret_cast<uint16_t*>(p);
   p += (size_t)max_frames * g.strips * kHistFused * 256 * 2;
   ws->spec = p;
+  ws->seq = 0;
 }
 
 hipError_t init_fwd_workspace(const FwdWorkspace& ws, hipStream_t s) {
+  hipError_t e = hipMemsetAsync(ws.ctr, 0, ws.zero_bytes, s);
+  if (e != hipSuccess) return e;
   return hipMemsetAsync(ws.spec, 3, 4, s);  // first guess: delta + CG
 }
 
@@ -2217,98 +2273,80 @@ hipError_t launch_split_decoded(const Geom& g, const uint16_t* d_img,
 template <bool SWAP>
 static hipError_t predict_impl(const Geom& g, const uint16_t* d_frames,
                                uint32_t nframes, const uint8_t* d_dhigh,
-                               const uint8_t* d_dlow, const FwdWorkspace& ws,
+                               const uint8_t* d_dlow, FwdWorkspace& ws,
                                uint8_t* d_high, uint8_t* d_low,
                                uint8_t* d_preview, uint8_t* d_flags,
                                hipStream_t s, hipEvent_t* ev) {
   const int with_delta = d_dhigh != nullptr;
-  hipError_t e;
-  if ((e = hipMemsetAsync(ws.counters, 0, ws.zero_fixed, s)) !=
-      hipSuccess)
-    return e;
+  StreamArgs a;
+  a.xs = g.xs; a.ys = g.ys; a.npix = g.npix; a.pw = g.pw; a.npv = g.npv;
+  a.strip_rows = g.strip_rows; a.strips = g.strips; a.ring_fwd = g.ring_fwd;
+  a.ring_base = g.ring_base; a.nacc = g.nacc; a.shift = (uint32_t)g.shift; a.nframes = nframes;
+  static const int strip_major = getenv("FPV_STRIP_MAJOR") ? atoi(getenv("FPV_STRIP_MAJOR")) : 1;
+  a.strip_major = (uint32_t)strip_major;
+  a.pwr = g.pwr; a.pvb_stride = g.pvb_stride; a.with_delta = (uint32_t)with_delta;
+  StreamPtrs P;
+  P.frames = d_frames; P.dhigh = d_dhigh; P.dlow = d_dlow;
+  P.high = d_high; P.low = d_low; P.preview = d_preview; P.flags = d_flags;
+  P.anylow = ws.anylow; P.frame_done = ws.frame_done; P.partials = ws.partials; P.pvb = ws.pvb;
+  P.ctr = ws.ctr + (ws.seq & 1u) * 64;
+  P.ctr_next = ws.ctr + ((ws.seq + 1) & 1u) * 64;
+  ws.seq++;
+  P.decision = ws.decision; P.list_a = ws.list_a; P.list_b = ws.list_b; P.spec = ws.spec;
+  const uint32_t waves = device_cus() * g.stream_waves_per_cu;
+  const uint32_t W = g.wg_waves;
+  a.wave_lds = g.wave_lds; a.wg_waves = W;
+  const uint32_t grid = std::min<uint32_t>((nframes + W - 1) / W * g.strips, waves / W);
+  const bool lowp = g.shift != 8;
   if (ev) hipEventRecord(ev[0], s);
-  {
-    static int ncu = 0;
-    if (!ncu) {
-      int dev = 0;
-      hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-        ncu = prop.multiProcessorCount;
-      if (ncu <= 0) ncu = 256;
-    }
-    const uint32_t ntasks = nframes * g.strips;
-    const uint32_t grid = std::min<uint32_t>(ntasks, (uint32_t)ncu * g.stream_waves_per_cu);
-    StreamArgs a;
-    a.xs = g.xs; a.ys = g.ys; a.npix = g.npix; a.pw = g.pw; a.npv = g.npv;
-    a.strip_rows = g.strip_rows; a.strips = g.strips; a.ring_fwd = g.ring_fwd;
-    a.ring_base = g.ring_base; a.nacc = g.nacc; a.shift = (uint32_t)g.shift; a.nframes = nframes;
-    static const int strip_major = getenv("FPV_STRIP_MAJOR") ? atoi(getenv("FPV_STRIP_MAJOR")) : 1;
-    a.strip_major = (uint32_t)strip_major;
-    // FAST needs every step of every strip to be full and a segment never to
-    // straddle image rows.  Both delta variants are launched; the one that does
-    // not match the speculation byte (device memory) exits at once.
-    const bool fast = (g.xs & 15) == 0 && g.nacc == 2 && (g.strip_rows * g.xs) % kStep == 0 &&
-                      g.ys % g.strip_rows == 0;
-#define FPV_LAUNCH_STREAM(F, D, L)                                                            \
-  k_stream<SWAP, F, D, L><<<grid, 64, g.wave_lds, s>>>(d_frames, d_dhigh, d_dlow, ws.spec,   \
-                                                       d_high, d_low, ws.pv_raw, ws.anylow,  \
-                                                       ws.partials, ws.counters, a)
-    const bool lowp = g.shift != 8;
-    if (fast) {
-      if (lowp) { FPV_LAUNCH_STREAM(true, false, true); if (with_delta) FPV_LAUNCH_STREAM(true, true, true); }
-      else { FPV_LAUNCH_STREAM(true, false, false); if (with_delta) FPV_LAUNCH_STREAM(true, true, false); }
-    } else {
-      if (lowp) { FPV_LAUNCH_STREAM(false, false, true); if (with_delta) FPV_LAUNCH_STREAM(false, true, true); }
-      else { FPV_LAUNCH_STREAM(false, false, false); if (with_delta) FPV_LAUNCH_STREAM(false, true, false); }
-    }
-#undef FPV_LAUNCH_STREAM
-  }
+#define FPV_LAUNCH(K, GRID, WAVES)                                                                    \
+  do {                                                                                                \
+    const uint32_t lds_ = (WAVES) * g.wave_lds + 16;                                                  \
+    if (g.fast) {                                                                                     \
+      if (lowp) K<SWAP, true, true><<<GRID, 64 * (WAVES), lds_, s>>>(P, a);                           \
+      else K<SWAP, true, false><<<GRID, 64 * (WAVES), lds_, s>>>(P, a);                               \
+    } else {                                                                                          \
+      if (lowp) K<SWAP, false, true><<<GRID, 64 * (WAVES), lds_, s>>>(P, a);                          \
+      else K<SWAP, false, false><<<GRID, 64 * (WAVES), lds_, s>>>(P, a);                              \
+    }                                                                                                 \
+  } while (0)
+  FPV_LAUNCH(k_stream, grid, W);
   if (ev) hipEventRecord(ev[1], s);
-  k_decide_spec<<<(nframes + kThreads / 64 - 1) / (kThreads / 64), kThreads, 0, s>>>(
-      ws.partials, ws.spec, ws.decision, ws.counters, ws.list_a, ws.list_b, g, with_delta, nframes);
-  if (ev) hipEventRecord(ev[2], s);
   // exact redo of mis-speculated frames; both launches exit at once when the lists are empty
-  k_redo_decide<SWAP><<<kListGrid / 4, kThreads, 0, s>>>(d_frames, d_dhigh, ws.decision, ws.counters,
-                                                        ws.list_a, ws.list_b, g, with_delta);
-  k_apply_list<SWAP><<<kListGrid, kThreads, g.lds_bytes, s>>>(
-      d_frames, d_dhigh, d_dlow, ws.decision, ws.counters, ws.list_b, d_high, d_low, ws.pv_raw,
-      ws.anylow, g);
+  k_redo_decide<SWAP><<<kListGrid, kThreads, 0, s>>>(d_frames, d_dhigh, ws.decision, P.ctr,
+                                                    ws.list_a, ws.list_b, g, with_delta);
+  if (ev) hipEventRecord(ev[2], s);
+  a.strip_rows = g.redo_strip_rows;
+  a.strips = g.redo_strips;
+  a.wg_waves = 1;
+  FPV_LAUNCH(k_redo_stream, waves, 1u);
+#undef FPV_LAUNCH
   if (ev) hipEventRecord(ev[3], s);
-  if ((g.pw & 15) == 0)
-    k_finish<true><<<dim3((g.npv / 16 + kThreads - 1) / kThreads, nframes), kThreads, 0, s>>>(
-        ws.pv_raw, ws.decision, ws.anylow, ws.counters, d_preview, d_flags, ws.spec, g);
-  else
-    k_finish<false><<<dim3((g.npv / 4 + kThreads) / kThreads, nframes), kThreads, 0, s>>>(
-        ws.pv_raw, ws.decision, ws.anylow, ws.counters, d_preview, d_flags, ws.spec, g);
   if (ev) hipEventRecord(ev[4], s);
   return hipGetLastError();
 }
 
 hipError_t launch_predict(const Geom& g, const uint16_t* d_frames,
                           uint32_t nframes, const uint8_t* d_dhigh,
-                          const uint8_t* d_dlow, const FwdWorkspace& ws,
+                          const uint8_t* d_dlow, FwdWorkspace& ws,
                           uint8_t* d_high, uint8_t* d_low, uint8_t* d_preview,
                           uint8_t* d_flags, hipStream_t s, hipEvent_t* ev) {
   static std::mutex attr_m;
   static uint64_t attr_done = 0;
-  once_per_device(attr_m, attr_done, [] {  // tiles above 64 KiB of LDS need the opt-in
-#define FPV_SF(W, F, D, L) reinterpret_cast<const void*>(&k_stream<W, F, D, L>)
+  once_per_device(attr_m, attr_done, [] {  // wide frames need more than 64 KiB of LDS per wave
+#define FPV_SF(K, W, F, L) reinterpret_cast<const void*>(&K<W, F, L>)
     const void* sf[16] = {
-        FPV_SF(true, true, true, true),    FPV_SF(true, true, true, false),
-        FPV_SF(true, true, false, true),   FPV_SF(true, true, false, false),
-        FPV_SF(true, false, true, true),   FPV_SF(true, false, true, false),
-        FPV_SF(true, false, false, true),  FPV_SF(true, false, false, false),
-        FPV_SF(false, true, true, true),   FPV_SF(false, true, true, false),
-        FPV_SF(false, true, false, true),  FPV_SF(false, true, false, false),
-        FPV_SF(false, false, true, true),  FPV_SF(false, false, true, false),
-        FPV_SF(false, false, false, true), FPV_SF(false, false, false, false)};
+        FPV_SF(k_stream, true, true, true),        FPV_SF(k_stream, true, true, false),
+        FPV_SF(k_stream, true, false, true),       FPV_SF(k_stream, true, false, false),
+        FPV_SF(k_stream, false, true, true),       FPV_SF(k_stream, false, true, false),
+        FPV_SF(k_stream, false, false, true),      FPV_SF(k_stream, false, false, false),
+        FPV_SF(k_redo_stream, true, true, true),   FPV_SF(k_redo_stream, true, true, false),
+        FPV_SF(k_redo_stream, true, false, true),  FPV_SF(k_redo_stream, true, false, false),
+        FPV_SF(k_redo_stream, false, true, true),  FPV_SF(k_redo_stream, false, true, false),
+        FPV_SF(k_redo_stream, false, false, true), FPV_SF(k_redo_stream, false, false, false)};
 #undef FPV_SF
     for (const void* f : sf)
-      hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    const void* fns[2] = {reinterpret_cast<const void*>(&k_apply_list<true>),
-                          reinterpret_cast<const void*>(&k_apply_list<false>)};
-    for (const void* f : fns)
-      hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+      hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxWaveLds);
   });
   if (g.swap)
     return predict_impl<true>(g, d_frames, nframes, d_dhigh, d_dlow, ws, d_high,
@@ -2344,15 +2382,8 @@ hipError_t launch_inverse(const Geom& g, const uint8_t* d_high,
     mode = e[0] == 'f' ? 1 : e[0] == 's' && e[1] == 'l' ? 2 : e[0] == 's' ? 0 : e[0] == 't' ? 3 : -1;
   }
   if (mode < 0) {
-    static int ncu = 0;
-    if (!ncu) {
-      int dev = 0;
-      hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-        ncu = prop.multiProcessorCount;
-      if (ncu <= 0) ncu = 256;
-    }
-    mode = nframes <= 3u * (uint32_t)ncu ? 3 : 0;
+    const uint32_t ncu = device_cus();
+    mode = nframes <= 3u * ncu ? 3 : 0;
   }
   const bool aligned = (g.xs & 3) == 0 && (g.npix & 3) == 0;
   if (mode == 3 && g.spec_k4) {

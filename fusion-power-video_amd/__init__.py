@@ -67,6 +67,8 @@ def _declare_hip(lib):
     lib.fpvhip_time_copy_device.argtypes = [vp, vp, c.c_size_t, vp, i32]
     lib.fpvhip_time_inverse_device.restype = c.c_double
     lib.fpvhip_time_inverse_device.argtypes = [vp, vp, vp, vp, u32, vp, vp, i32]
+    lib.fpvhip_debug_counters.restype = i32
+    lib.fpvhip_debug_counters.argtypes = [vp, c.POINTER(c.c_uint32), u32]
     lib.fpvhip_inverse_pass_stats.restype = i32
     lib.fpvhip_inverse_pass_stats.argtypes = [vp, c.POINTER(c.c_uint32), i32]
     for name in ("fpvhip_set_delta_raw", "fpvhip_set_delta_decoded", "fpvhip_predict_submit",
@@ -213,6 +215,18 @@ class Predictor:
         if ms < 0:
             raise FpvError("time_predict: " + _err(self.ctx))
         return (ms, list(km)) if per_kernel else ms
+
+    def debug_counters(self, n=16):
+        """Counter block of the last forward batch: [0] frames whose delta decision was
+        mis-speculated, [1] frames redone under their true flags, [4..7] decisions by value."""
+        buf = (ctypes.c_uint32 * n)()
+        self._check(self.lib.fpvhip_debug_counters(self.ctx, buf, n), "debug_counters")
+        return [int(v) for v in buf]
+
+    def inverse_kernel_name(self, nframes):
+        """Which inverse kernel launch_inverse picks for this batch size (FPV_INVERSE unset)."""
+        cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+        return "k_inverse_trio" if nframes <= 3 * cus else "k_inverse_spec"
 
     def inverse_pass_stats(self, reset=True):
         """(supersteps, passes) of the speculative inverse kernel since the last reset;

@@ -3,6 +3,7 @@
 
 #include <string.h>
 
+#include <chrono>
 #include <vector>
 
 #include "fusion_power_video.h"
@@ -44,6 +45,34 @@ void fpvc_encoder_finish(void* enc, fpvc_write_fn cb, void* payload) {
   static_cast<fpvc::Encoder*>(enc)->Finish(cb, payload);
 }
 void fpvc_encoder_free(void* enc) { delete static_cast<fpvc::Encoder*>(enc); }
+size_t fpvc_encoder_stats(const void* enc, double* out, size_t n) {
+  return static_cast<const fpvc::Encoder*>(enc)->LastStats(out, n);
+}
+
+// Encoder construction -> Finish over `total` frames that cycle through `distinct`
+// resident ones, timed like the upstream benchmark times it (benchmark.cc:153-180); the
+// callbacks copy every chunk away as the upstream tools do.  Returns the seconds.
+double fpvc_bench_encode(const uint16_t* frames, size_t distinct, size_t total, size_t xs, size_t ys,
+                         int shift, int big_endian, size_t num_threads, size_t* bytes_out,
+                         double* stats, size_t nstats) {
+  struct Out { std::vector<uint8_t> last; size_t bytes; } out = {{}, 0};
+  auto cb = [](const uint8_t* d, size_t n, void* p) {
+    Out* o = static_cast<Out*>(p);
+    o->last.assign(d, d + n);
+    o->bytes += n;
+  };
+  const auto t0 = std::chrono::steady_clock::now();
+  {
+    fpvc::Encoder enc(num_threads, shift, big_endian != 0);
+    enc.Init(frames, xs, ys, cb, &out);
+    for (size_t i = 0; i < total; i++) enc.CompressFrame(frames + (i % distinct) * xs * ys, cb, &out);
+    enc.Finish(cb, &out);
+    if (stats) enc.LastStats(stats, nstats);
+  }
+  const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (bytes_out) *bytes_out = out.bytes;
+  return dt;
+}
 
 size_t fpvc_encode_stream(const uint16_t* frames, size_t nframes,
                           const uint16_t* delta_raw, size_t xs, size_t ys, int shift,

@@ -4,7 +4,13 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <time.h>
+
+#include <atomic>
+#include <mutex>
 
 #include <new>
 #include <vector>
@@ -19,10 +25,56 @@ namespace {
 
 thread_local char g_err[256] = "";
 
+// Host staging memory of one slot: ONE region, anonymous pages (transparent huge pages
+// where the system grants them) touched once and then registered with the runtime.
+// On this platform that is 5-20x cheaper than hipHostMalloc of the same size
+// (tools/exp/pin_bench.cc: 66 MB in 1-3 ms against 11-13 ms) and copies run at the
+// same rate; hipHostMalloc is the fallback when registration is refused.
+struct PinnedRegion {
+  void* base = nullptr;
+  size_t bytes = 0;
+  bool registered = false;  // mmap + hipHostRegister (else hipHostMalloc)
+};
+
+int pinned_alloc(PinnedRegion* r, size_t bytes) {
+  r->bytes = (bytes + 4095) & ~(size_t)4095;
+  if (!getenv("FPV_NO_HOST_REGISTER")) {
+    void* p = mmap(nullptr, r->bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (p != MAP_FAILED) {
+      madvise(p, r->bytes, MADV_HUGEPAGE);
+      volatile char* c = static_cast<volatile char*>(p);
+      for (size_t o = 0; o < r->bytes; o += 4096) c[o] = 0;  // populate before pinning: registering untouched pages is slow
+      if (hipHostRegister(p, r->bytes, hipHostRegisterDefault) == hipSuccess) {
+        r->base = p;
+        r->registered = true;
+        return 0;
+      }
+      (void)hipGetLastError();
+      munmap(p, r->bytes);
+    }
+  }
+  r->registered = false;
+  return hipHostMalloc(&r->base, r->bytes, hipHostMallocDefault) == hipSuccess ? 0 : -1;
+}
+
+void pinned_free(PinnedRegion* r) {
+  if (!r->base) return;
+  if (r->registered) {
+    hipHostUnregister(r->base);
+    munmap(r->base, r->bytes);
+  } else {
+    hipHostFree(r->base);
+  }
+  *r = PinnedRegion();
+}
+
 struct Slot {
-  hipStream_t stream = nullptr;
-  hipEvent_t done = nullptr;
-  hipEvent_t begin = nullptr;  // recorded in front of a batch's first transfer (stage timing)
+  hipEvent_t done = nullptr;     // last transfer out has finished
+  hipEvent_t begin = nullptr;    // recorded in front of a batch's first transfer (stage timing)
+  hipEvent_t up_done = nullptr;  // transfers in have finished
+  hipEvent_t k_done = nullptr;   // kernels have finished
+  PinnedRegion host;
+  void* dev = nullptr;           // one device allocation, carved like the host region
   // pinned host
   uint16_t* h_pix = nullptr;  // [B][npix]  forward input / inverse output
   uint8_t* h_high = nullptr;  // [B][npix]  forward output / inverse input
@@ -38,8 +90,45 @@ struct Slot {
   void* d_ws = nullptr;
   FwdWorkspace ws{};
   uint32_t pending = 0;  // frames of the batch in flight
-  bool ready = false;    // buffers allocated (slots after the first are allocated on first use)
+  std::atomic<bool> ready{false};  // buffers allocated (slots after the first are allocated on first use)
+  std::mutex alloc_m;              // one allocator at a time per slot; different slots allocate side by side
 };
+
+// Streams are expensive to create (3-10 ms each on this platform) and do not depend on the
+// frame geometry: a process-wide pool per device, filled by fpvhip_warmup, lends them to
+// the contexts.
+struct StreamPool {
+  std::mutex m;
+  std::vector<hipStream_t> idle[64];
+};
+StreamPool& stream_pool() {
+  static StreamPool* p = new StreamPool();  // leaked on purpose (no HIP calls during static destruction)
+  return *p;
+}
+hipStream_t take_stream(int dev) {
+  StreamPool& p = stream_pool();
+  {
+    std::lock_guard<std::mutex> l(p.m);
+    auto& v = p.idle[dev & 63];
+    if (!v.empty()) {
+      hipStream_t s = v.back();
+      v.pop_back();
+      return s;
+    }
+  }
+  hipStream_t s = nullptr;
+  if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+  return s;
+}
+void give_stream(int dev, hipStream_t s) {
+  if (!s) return;
+  hipStreamSynchronize(s);
+  StreamPool& p = stream_pool();
+  std::lock_guard<std::mutex> l(p.m);
+  if (p.idle[dev & 63].size() < 16) p.idle[dev & 63].push_back(s);
+  else hipStreamDestroy(s);
+}
+
 
 }  // namespace
 
@@ -47,13 +136,21 @@ struct fpvhip_ctx {
   int device = 0;
   Geom g{};
   uint32_t max_batch = 0;
-  std::vector<Slot> slots;
+  Slot* slots = nullptr;
+  uint32_t nslots = 0;
+  // All transfers in share one stream and all transfers out another: the two directions of
+  // the host link then run at the same time (48 GB/s each way measured against 23-29 GB/s
+  // when every slot copies in and out on its own stream).  Events chain a batch's
+  // copy in -> kernels (one compute stream per context) -> copy out.
+  hipStream_t up = nullptr, comp = nullptr, down = nullptr;
+  std::mutex xfer_m;  // enqueue order on the three streams
   // delta frame
   uint8_t* d_dhigh = nullptr;
   uint8_t* d_dlow = nullptr;
   uint16_t* d_dtmp = nullptr;  // upload buffer for set_delta_*
   uint32_t* d_inv_diag = nullptr;  // speculative inverse: supersteps, passes (diagnostics)
   bool have_delta = false;
+  int timing_left = 3;  // FPV_TIMING: the first few batches are reported
   // workspace of the device-resident entry points
   void* d_ws = nullptr;
   FwdWorkspace ws{};
@@ -82,53 +179,65 @@ int fail(fpvhip_ctx* c, const char* fmt, ...) {
                   __FILE__, __LINE__);                                        \
   } while (0)
 
+double now_ms() {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec * 1e3 + ts.tv_nsec / 1e6;
+}
+const bool g_timing = getenv("FPV_TIMING") != nullptr;
+
 int alloc_slot(fpvhip_ctx* c, Slot* s) {
+  const double t_begin = now_ms();
   const size_t B = c->max_batch, np = c->g.npix, nv = c->g.npv;
-  HIPOK(c, hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  auto up16 = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t o_pix = 0, o_high = o_pix + up16(B * np * 2), o_low = o_high + up16(B * np),
+               o_pv = o_low + up16(B * np), o_flags = o_pv + up16(B * nv), total = o_flags + up16(B);
   HIPOK(c, hipEventCreate(&s->done));
   HIPOK(c, hipEventCreate(&s->begin));
-  HIPOK(c, hipHostMalloc(reinterpret_cast<void**>(&s->h_pix), B * np * 2, hipHostMallocDefault));
-  HIPOK(c, hipHostMalloc(reinterpret_cast<void**>(&s->h_high), B * np, hipHostMallocDefault));
-  HIPOK(c, hipHostMalloc(reinterpret_cast<void**>(&s->h_low), B * np, hipHostMallocDefault));
-  HIPOK(c, hipHostMalloc(reinterpret_cast<void**>(&s->h_pv), B * nv, hipHostMallocDefault));
-  HIPOK(c, hipHostMalloc(reinterpret_cast<void**>(&s->h_flags), B, hipHostMallocDefault));
-  HIPOK(c, hipMalloc(reinterpret_cast<void**>(&s->d_pix), B * np * 2));
-  HIPOK(c, hipMalloc(reinterpret_cast<void**>(&s->d_high), B * np));
-  HIPOK(c, hipMalloc(reinterpret_cast<void**>(&s->d_low), B * np));
-  HIPOK(c, hipMalloc(reinterpret_cast<void**>(&s->d_pv), B * nv));
-  HIPOK(c, hipMalloc(reinterpret_cast<void**>(&s->d_flags), B));
+  HIPOK(c, hipEventCreateWithFlags(&s->up_done, hipEventDisableTiming));
+  HIPOK(c, hipEventCreateWithFlags(&s->k_done, hipEventDisableTiming));
+  const double t_host = now_ms();
+  if (pinned_alloc(&s->host, total)) return fail(c, "cannot allocate %zu bytes of pinned staging memory", total);
+  const double t_host_done = now_ms();
+  uint8_t* h = static_cast<uint8_t*>(s->host.base);
+  s->h_pix = reinterpret_cast<uint16_t*>(h + o_pix);
+  s->h_high = h + o_high; s->h_low = h + o_low; s->h_pv = h + o_pv; s->h_flags = h + o_flags;
+  HIPOK(c, hipMalloc(&s->dev, total));
+  uint8_t* d = static_cast<uint8_t*>(s->dev);
+  s->d_pix = reinterpret_cast<uint16_t*>(d + o_pix);
+  s->d_high = d + o_high; s->d_low = d + o_low; s->d_pv = d + o_pv; s->d_flags = d + o_flags;
   if (c->g.fwd_ok) {
     HIPOK(c, hipMalloc(&s->d_ws, fpvhip::fwd_workspace_bytes(c->g, c->max_batch)));
     fpvhip::carve_fwd_workspace(c->g, c->max_batch, s->d_ws, &s->ws);
-    HIPOK(c, fpvhip::init_fwd_workspace(s->ws, s->stream));
+    std::lock_guard<std::mutex> l(c->xfer_m);
+    HIPOK(c, fpvhip::init_fwd_workspace(s->ws, c->comp));  // stream order: ahead of the slot's first batch
   }
-  s->ready = true;
+  s->ready.store(true, std::memory_order_release);
+  if (g_timing)
+    fprintf(stderr, "fpv-mi355x: slot: events %.2f ms, %zu MB pinned (%s) %.2f ms, device + workspace %.2f ms\n",
+            t_host - t_begin, total >> 20, s->host.registered ? "mmap + register" : "hipHostMalloc", t_host_done - t_host,
+            now_ms() - t_host_done);
   return 0;
 }
 
 void free_slot(Slot* s) {
-  if (s->stream) hipStreamSynchronize(s->stream);
-  hipHostFree(s->h_pix); hipHostFree(s->h_high); hipHostFree(s->h_low);
-  hipHostFree(s->h_pv); hipHostFree(s->h_flags);
-  hipFree(s->d_pix); hipFree(s->d_high); hipFree(s->d_low);
-  hipFree(s->d_pv); hipFree(s->d_flags); hipFree(s->d_ws);
-  if (s->done) hipEventDestroy(s->done);
-  if (s->begin) hipEventDestroy(s->begin);
-  if (s->stream) hipStreamDestroy(s->stream);
-  *s = Slot();
+  pinned_free(&s->host);
+  hipFree(s->dev); hipFree(s->d_ws);
+  for (hipEvent_t e : {s->done, s->begin, s->up_done, s->k_done})
+    if (e) hipEventDestroy(e);
 }
 
-// Pinned allocations are slow (tens of ms per slot): only slot 0 is allocated
-// by create; the others when they are first touched, which in the encoder
-// pipeline overlaps with the GPU and Brotli work of the batches before.
+// Only slot 0 is allocated by create; the others when they are first touched,
+// which in the encoder pipeline overlaps with the GPU and Brotli work of the
+// batches before (a slot costs a few ms: see PinnedRegion).
 int check_slot(fpvhip_ctx* c, uint32_t slot) {
   if (!c) return fail(nullptr, "null context");
-  if (slot >= c->slots.size()) return fail(c, "slot %u out of range", slot);
-  if (!c->slots[slot].ready) {
-    if (hipSetDevice(c->device) != hipSuccess) return fail(c, "hipSetDevice failed");
-    if (alloc_slot(c, &c->slots[slot])) return -1;
-  }
-  return 0;
+  if (slot >= c->nslots) return fail(c, "slot %u out of range", slot);
+  if (c->slots[slot].ready.load(std::memory_order_acquire)) return 0;
+  std::lock_guard<std::mutex> l(c->slots[slot].alloc_m);
+  if (c->slots[slot].ready.load(std::memory_order_acquire)) return 0;
+  if (hipSetDevice(c->device) != hipSuccess) return fail(c, "hipSetDevice failed");
+  return alloc_slot(c, &c->slots[slot]);
 }
 
 }  // namespace
@@ -172,6 +281,7 @@ static fpvhip_ctx* create_impl(int device, const Geom& g, uint32_t max_batch,
   c->g = g;
   c->max_batch = max_batch;
   auto setup = [&]() -> int {
+    const double t0 = now_ms();
     HIPOK(c, hipSetDevice(device));
     HIPOK(c, hipMalloc(reinterpret_cast<void**>(&c->d_dhigh), g.npix));
     HIPOK(c, hipMalloc(reinterpret_cast<void**>(&c->d_dlow), g.npix));
@@ -185,8 +295,17 @@ static fpvhip_ctx* create_impl(int device, const Geom& g, uint32_t max_batch,
       HIPOK(c, hipStreamSynchronize(nullptr));
     }
     for (auto& e : c->ev) HIPOK(c, hipEventCreate(&e));
-    c->slots.resize(slots);
+    const double t1 = now_ms();
+    c->up = take_stream(device); c->comp = take_stream(device); c->down = take_stream(device);
+    if (!c->up || !c->comp || !c->down) return fail(c, "cannot create HIP streams");
+    c->slots = new (std::nothrow) Slot[slots ? slots : 1];
+    if (!c->slots) return fail(c, "out of memory");
+    c->nslots = slots;
+    const double t2 = now_ms();
     if (slots && alloc_slot(c, &c->slots[0])) return -1;
+    if (g_timing)
+      fprintf(stderr, "fpv-mi355x: create: device buffers + workspace + events %.2f ms, streams %.2f ms, slot 0 %.2f ms\n",
+              t1 - t0, t2 - t1, now_ms() - t2);
     return 0;
   };
   if (setup()) {
@@ -222,7 +341,11 @@ fpvhip_ctx* fpvhip_create_decoder(int device, uint32_t xs, uint32_t ys,
 void fpvhip_destroy(fpvhip_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);
-  for (auto& s : c->slots) free_slot(&s);
+  for (hipStream_t st : {c->up, c->comp, c->down})
+    if (st) hipStreamSynchronize(st);
+  for (uint32_t k = 0; k < c->nslots; k++) free_slot(&c->slots[k]);
+  delete[] c->slots;
+  give_stream(c->device, c->up); give_stream(c->device, c->comp); give_stream(c->device, c->down);
   hipFree(c->d_dhigh); hipFree(c->d_dlow); hipFree(c->d_dtmp); hipFree(c->d_ws); hipFree(c->d_inv_diag);
   for (auto& e : c->ev) if (e) hipEventDestroy(e);
   delete c;
@@ -231,15 +354,26 @@ void fpvhip_destroy(fpvhip_ctx* c) {
 size_t fpvhip_npix(const fpvhip_ctx* c) { return c ? c->g.npix : 0; }
 size_t fpvhip_npreview(const fpvhip_ctx* c) { return c ? c->g.npv : 0; }
 uint32_t fpvhip_max_batch(const fpvhip_ctx* c) { return c ? c->max_batch : 0; }
-uint32_t fpvhip_slots(const fpvhip_ctx* c) { return c ? (uint32_t)c->slots.size() : 0; }
+uint32_t fpvhip_slots(const fpvhip_ctx* c) { return c ? c->nslots : 0; }
+
+int fpvhip_prepare_slot(fpvhip_ctx* c, uint32_t slot) { return check_slot(c, slot); }
 
 int fpvhip_set_delta_raw(fpvhip_ctx* c, const uint16_t* delta_raw) {
   if (!c || !delta_raw) return fail(c, "null argument");
   if (!c->g.fwd_ok) return fail(c, "decoder-only context");
+  const double t0 = now_ms();
   HIPOK(c, hipSetDevice(c->device));
-  HIPOK(c, hipMemcpy(c->d_dtmp, delta_raw, (size_t)c->g.npix * 2, hipMemcpyHostToDevice));
+  // through pinned staging when a slot exists: the first pageable copy of a process costs ~7 ms
+  if (c->nslots && c->slots[0].ready.load() && !c->slots[0].pending) {
+    memcpy(c->slots[0].h_pix, delta_raw, (size_t)c->g.npix * 2);
+    HIPOK(c, hipMemcpy(c->d_dtmp, c->slots[0].h_pix, (size_t)c->g.npix * 2, hipMemcpyHostToDevice));
+  } else {
+    HIPOK(c, hipMemcpy(c->d_dtmp, delta_raw, (size_t)c->g.npix * 2, hipMemcpyHostToDevice));
+  }
+  const double t1 = now_ms();
   HIPOK(c, fpvhip::launch_split(c->g, c->d_dtmp, c->d_dhigh, c->d_dlow, nullptr, nullptr));
   HIPOK(c, hipStreamSynchronize(nullptr));
+  if (g_timing) fprintf(stderr, "fpv-mi355x: set_delta_raw: copy %.2f ms, split %.2f ms\n", t1 - t0, now_ms() - t1);
   c->have_delta = true;
   return 0;
 }
@@ -269,20 +403,23 @@ int fpvhip_set_delta_planes(fpvhip_ctx* c, const uint8_t* high, const uint8_t* l
 int fpvhip_split_frame(fpvhip_ctx* c, const uint16_t* img, uint8_t* high, uint8_t* low,
                        int* no_low) {
   if (!c || !img || !high || !no_low) return fail(c, "null argument");
-  if (!c->g.fwd_ok || c->slots.empty()) return fail(c, "needs a forward context with a slot");
+  if (!c->g.fwd_ok || c->nslots == 0) return fail(c, "needs a forward context with a slot");
   Slot& s = c->slots[0];
   const size_t np = c->g.npix;
   HIPOK(c, hipSetDevice(c->device));
-  HIPOK(c, hipMemcpyAsync(s.d_pix, img, np * 2, hipMemcpyHostToDevice, s.stream));
-  HIPOK(c, hipMemsetAsync(s.ws.anylow, 0, 4, s.stream));
-  HIPOK(c, fpvhip::launch_split(c->g, s.d_pix, s.d_high, s.d_low, s.ws.anylow, s.stream));
-  HIPOK(c, hipMemcpyAsync(high, s.d_high, np, hipMemcpyDeviceToHost, s.stream));
-  if (low && c->g.shift != 8)
-    HIPOK(c, hipMemcpyAsync(low, s.d_low, np, hipMemcpyDeviceToHost, s.stream));
   uint32_t any = 0;
-  HIPOK(c, hipMemcpyAsync(&any, s.ws.anylow, 4, hipMemcpyDeviceToHost, s.stream));
-  HIPOK(c, hipMemsetAsync(s.ws.anylow, 0, 4, s.stream));  // the predictor expects its accumulators clean
-  HIPOK(c, hipStreamSynchronize(s.stream));
+  {
+    std::lock_guard<std::mutex> l(c->xfer_m);
+    HIPOK(c, hipMemcpyAsync(s.d_pix, img, np * 2, hipMemcpyHostToDevice, c->comp));
+    HIPOK(c, hipMemsetAsync(s.ws.anylow, 0, 4, c->comp));
+    HIPOK(c, fpvhip::launch_split(c->g, s.d_pix, s.d_high, s.d_low, s.ws.anylow, c->comp));
+    HIPOK(c, hipMemcpyAsync(high, s.d_high, np, hipMemcpyDeviceToHost, c->comp));
+    if (low && c->g.shift != 8)
+      HIPOK(c, hipMemcpyAsync(low, s.d_low, np, hipMemcpyDeviceToHost, c->comp));
+    HIPOK(c, hipMemcpyAsync(&any, s.ws.anylow, 4, hipMemcpyDeviceToHost, c->comp));
+    HIPOK(c, hipMemsetAsync(s.ws.anylow, 0, 4, c->comp));  // the predictor expects its accumulators clean
+  }
+  HIPOK(c, hipStreamSynchronize(c->comp));
   *no_low = any == 0;
   return 0;
 }
@@ -313,25 +450,32 @@ static int predict_submit_impl(fpvhip_ctx* c, uint32_t slot, uint32_t nframes, i
   Slot& s = c->slots[slot];
   const size_t np = c->g.npix, nv = c->g.npv;
   HIPOK(c, hipSetDevice(c->device));
-  HIPOK(c, hipEventRecord(s.begin, s.stream));
+  const double t_sub = now_ms();
+  std::lock_guard<std::mutex> l(c->xfer_m);
+  HIPOK(c, hipEventRecord(s.begin, c->up));
   if (from_planes) {  // planes staged in h_high / h_low -> pixels on the device
-    HIPOK(c, hipMemcpyAsync(s.d_high, s.h_high, nframes * np, hipMemcpyHostToDevice, s.stream));
-    HIPOK(c, hipMemcpyAsync(s.d_low, s.h_low, nframes * np, hipMemcpyHostToDevice, s.stream));
-    HIPOK(c, fpvhip::launch_interleave(s.d_high, s.d_low, s.d_pix, nframes * np, s.stream));
+    HIPOK(c, hipMemcpyAsync(s.d_high, s.h_high, nframes * np, hipMemcpyHostToDevice, c->up));
+    HIPOK(c, hipMemcpyAsync(s.d_low, s.h_low, nframes * np, hipMemcpyHostToDevice, c->up));
   } else {
-    HIPOK(c, hipMemcpyAsync(s.d_pix, s.h_pix, nframes * np * 2, hipMemcpyHostToDevice, s.stream));
+    HIPOK(c, hipMemcpyAsync(s.d_pix, s.h_pix, nframes * np * 2, hipMemcpyHostToDevice, c->up));
   }
+  HIPOK(c, hipEventRecord(s.up_done, c->up));
+  HIPOK(c, hipStreamWaitEvent(c->comp, s.up_done, 0));
+  if (from_planes) HIPOK(c, fpvhip::launch_interleave(s.d_high, s.d_low, s.d_pix, nframes * np, c->comp));
   HIPOK(c, fpvhip::launch_predict(c->g, s.d_pix, nframes,
                                   with_delta ? c->d_dhigh : nullptr,
                                   with_delta ? c->d_dlow : nullptr, s.ws, s.d_high,
-                                  s.d_low, s.d_pv, s.d_flags, s.stream, nullptr));
-  HIPOK(c, hipMemcpyAsync(s.h_high, s.d_high, nframes * np, hipMemcpyDeviceToHost, s.stream));
+                                  s.d_low, s.d_pv, s.d_flags, c->comp, nullptr));
+  HIPOK(c, hipEventRecord(s.k_done, c->comp));
+  HIPOK(c, hipStreamWaitEvent(c->down, s.k_done, 0));
+  HIPOK(c, hipMemcpyAsync(s.h_high, s.d_high, nframes * np, hipMemcpyDeviceToHost, c->down));
   if (c->g.shift != 8)
-    HIPOK(c, hipMemcpyAsync(s.h_low, s.d_low, nframes * np, hipMemcpyDeviceToHost, s.stream));
-  HIPOK(c, hipMemcpyAsync(s.h_pv, s.d_pv, nframes * nv, hipMemcpyDeviceToHost, s.stream));
-  HIPOK(c, hipMemcpyAsync(s.h_flags, s.d_flags, nframes, hipMemcpyDeviceToHost, s.stream));
-  HIPOK(c, hipEventRecord(s.done, s.stream));
+    HIPOK(c, hipMemcpyAsync(s.h_low, s.d_low, nframes * np, hipMemcpyDeviceToHost, c->down));
+  HIPOK(c, hipMemcpyAsync(s.h_pv, s.d_pv, nframes * nv, hipMemcpyDeviceToHost, c->down));
+  HIPOK(c, hipMemcpyAsync(s.h_flags, s.d_flags, nframes, hipMemcpyDeviceToHost, c->down));
+  HIPOK(c, hipEventRecord(s.done, c->down));
   s.pending = nframes;
+  if (g_timing && c->timing_left > 0) fprintf(stderr, "fpv-mi355x: predict_submit(%u frames): enqueue %.2f ms\n", nframes, now_ms() - t_sub);
   return 0;
 }
 
@@ -341,7 +485,14 @@ int fpvhip_predict_wait(fpvhip_ctx* c, uint32_t slot, const uint8_t** high,
   if (check_slot(c, slot)) return -1;
   Slot& s = c->slots[slot];
   if (!s.pending) return fail(c, "slot %u has nothing in flight", slot);
+  const double t_w = now_ms();
   HIPOK(c, hipEventSynchronize(s.done));
+  if (g_timing && c->timing_left > 0) {
+    c->timing_left--;
+    float ms = 0;
+    hipEventElapsedTime(&ms, s.begin, s.done);
+    fprintf(stderr, "fpv-mi355x: predict_wait: blocked %.2f ms, device begin->done %.2f ms\n", now_ms() - t_w, ms);
+  }
   s.pending = 0;
   if (high) *high = s.h_high;
   if (low) *low = s.h_low;
@@ -390,25 +541,31 @@ static int inverse_submit_impl(fpvhip_ctx* c, uint32_t slot, uint32_t nframes,
     if ((flags[k] & 1) && !c->have_delta) return fail(c, "delta frame not given");  // cc:310
   }
   HIPOK(c, hipSetDevice(c->device));
-  HIPOK(c, hipEventRecord(s.begin, s.stream));
-  HIPOK(c, hipMemcpyAsync(s.d_high, s.h_high, nframes * np, hipMemcpyHostToDevice, s.stream));
+  std::lock_guard<std::mutex> l(c->xfer_m);
+  HIPOK(c, hipEventRecord(s.begin, c->up));
+  HIPOK(c, hipMemcpyAsync(s.d_high, s.h_high, nframes * np, hipMemcpyHostToDevice, c->up));
   if (any_low)
-    HIPOK(c, hipMemcpyAsync(s.d_low, s.h_low, nframes * np, hipMemcpyHostToDevice, s.stream));
-  HIPOK(c, hipMemcpyAsync(s.d_flags, s.h_flags, nframes, hipMemcpyHostToDevice, s.stream));
+    HIPOK(c, hipMemcpyAsync(s.d_low, s.h_low, nframes * np, hipMemcpyHostToDevice, c->up));
+  HIPOK(c, hipMemcpyAsync(s.d_flags, s.h_flags, nframes, hipMemcpyHostToDevice, c->up));
+  HIPOK(c, hipEventRecord(s.up_done, c->up));
+  HIPOK(c, hipStreamWaitEvent(c->comp, s.up_done, 0));
   HIPOK(c, fpvhip::launch_inverse(c->g, s.d_high, s.d_low,
                                   c->have_delta ? c->d_dhigh : nullptr,
                                   c->have_delta ? c->d_dlow : nullptr, s.d_flags,
-                                  nframes, s.d_pix, s.stream, c->d_inv_diag));
-  if (to_planes) {  // (pixel >> 8, pixel & 0xff) back into the plane staging buffers
-    HIPOK(c, fpvhip::launch_split_planes(s.d_pix, s.d_high, s.d_low, nframes * np, s.stream));
-    HIPOK(c, hipMemcpyAsync(s.h_high, s.d_high, nframes * np, hipMemcpyDeviceToHost, s.stream));
-    HIPOK(c, hipMemcpyAsync(s.h_low, s.d_low, nframes * np, hipMemcpyDeviceToHost, s.stream));
+                                  nframes, s.d_pix, c->comp, c->d_inv_diag));
+  if (to_planes)  // (pixel >> 8, pixel & 0xff) back into the plane staging buffers
+    HIPOK(c, fpvhip::launch_split_planes(s.d_pix, s.d_high, s.d_low, nframes * np, c->comp));
+  else if (unshift >= 0)  // UnextractFrame (cc:850-862) fused in front of the copy back
+    HIPOK(c, fpvhip::launch_unextract(s.d_pix, nframes * np, unshift, big_endian, c->comp));
+  HIPOK(c, hipEventRecord(s.k_done, c->comp));
+  HIPOK(c, hipStreamWaitEvent(c->down, s.k_done, 0));
+  if (to_planes) {
+    HIPOK(c, hipMemcpyAsync(s.h_high, s.d_high, nframes * np, hipMemcpyDeviceToHost, c->down));
+    HIPOK(c, hipMemcpyAsync(s.h_low, s.d_low, nframes * np, hipMemcpyDeviceToHost, c->down));
   } else {
-    if (unshift >= 0)  // UnextractFrame (cc:850-862) fused in front of the copy back
-      HIPOK(c, fpvhip::launch_unextract(s.d_pix, nframes * np, unshift, big_endian, s.stream));
-    HIPOK(c, hipMemcpyAsync(s.h_pix, s.d_pix, nframes * np * 2, hipMemcpyDeviceToHost, s.stream));
+    HIPOK(c, hipMemcpyAsync(s.h_pix, s.d_pix, nframes * np * 2, hipMemcpyDeviceToHost, c->down));
   }
-  HIPOK(c, hipEventRecord(s.done, s.stream));
+  HIPOK(c, hipEventRecord(s.done, c->down));
   s.pending = nframes;
   return 0;
 }
@@ -506,6 +663,16 @@ int fpvhip_warmup(int device) {
   HIPOK(nullptr, fpvhip::launch_copy(p, p, 0, nullptr));  // loads the code object
   HIPOK(nullptr, hipDeviceSynchronize());
   HIPOK(nullptr, hipFree(p));
+  // streams are slow to create (the first one of a process tens of ms, later ones 3-10 ms):
+  // a context's worth of them goes into the pool; so does the first host registration
+  {
+    hipStream_t st[3] = {nullptr, nullptr, nullptr};
+    for (auto& x : st) x = take_stream(device);
+    for (auto& x : st) give_stream(device, x);
+  }
+  fpvhip::prepare_kernels();  // function attributes of the forward / inverse kernels on this device
+  PinnedRegion r;
+  if (pinned_alloc(&r, 1 << 16) == 0) pinned_free(&r);
   return 0;
 }
 
@@ -517,7 +684,7 @@ int fpvhip_debug_counters(fpvhip_ctx* c, uint32_t* out, uint32_t n) {
 }
 
 double fpvhip_slot_elapsed_ms(fpvhip_ctx* c, uint32_t slot) {
-  if (!c || slot >= c->slots.size() || !c->slots[slot].ready || c->slots[slot].pending) return -1.0;
+  if (!c || slot >= c->nslots || !c->slots[slot].ready.load() || c->slots[slot].pending) return -1.0;
   float ms = -1.f;
   if (hipEventElapsedTime(&ms, c->slots[slot].begin, c->slots[slot].done) != hipSuccess) return -1.0;
   return ms;

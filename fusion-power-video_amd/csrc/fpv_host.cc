@@ -229,20 +229,34 @@ size_t EnvSize(const char* name, size_t dflt) {
 // One frame chunk (OutputFull, cc:830-846) from predicted planes:
 //   u32 total | 0x00 | u32 (1 + len(preview stream)) | (flags & CG) | NO_LOW |
 //   brotli(preview) | flags | [brotli(low)] | brotli(high)
+// Built in a scratch buffer that lives as long as its worker thread (sized once for the
+// worst case) and returned as an exact-size copy: megabyte-sized vectors that grow while
+// Brotli appends to them made every frame pay for several mmap / munmap calls, which many
+// threads doing it at once serialise on.
 void BuildFrameChunk(const uint8_t* high, const uint8_t* low, const uint8_t* preview,
                      uint8_t flags, size_t npix, size_t npv,
                      std::vector<uint8_t>* out) {
-  out->clear();
-  out->reserve(npix + npix / 2);
-  out->resize(9);
-  out->push_back((uint8_t)((flags & USE_CG) | NO_LOW_BYTES));  // cc:842
-  if (!BrotliAppend(preview, npv, out)) Fatal("Brotli", "preview plane");
-  Store32((uint32_t)(out->size() - 9), out->data() + 5);  // preview stream + its flags byte
-  out->push_back(flags);                                      // cc:825
-  if (!(flags & NO_LOW_BYTES) && !BrotliAppend(low, npix, out)) Fatal("Brotli", "low plane");
-  if (!BrotliAppend(high, npix, out)) Fatal("Brotli", "high plane");
-  Store32((uint32_t)out->size(), out->data());
-  (*out)[4] = 0;  // chunk flag: ordinary frame (cc:840)
+  static thread_local std::vector<uint8_t> scratch;
+  const size_t cap_pv = std::max<size_t>(BrotliEncoderMaxCompressedSize(npv), npv + 1024);
+  const size_t cap_pl = std::max<size_t>(BrotliEncoderMaxCompressedSize(npix), npix + 1024);
+  const size_t need = 16 + cap_pv + 2 * cap_pl;
+  if (scratch.size() < need) scratch.resize(need);
+  uint8_t* p = scratch.data();
+  size_t at = 9;
+  p[at++] = (uint8_t)((flags & USE_CG) | NO_LOW_BYTES);  // cc:842
+  auto brotli = [&](const uint8_t* in, size_t n, size_t cap, const char* what) {
+    size_t sz = cap;  // cc:653: quality 1, default window (22), default mode; one shot per plane
+    if (!BrotliEncoderCompress(1, BROTLI_DEFAULT_WINDOW, BROTLI_DEFAULT_MODE, n, in, &sz, p + at)) Fatal("Brotli", what);
+    at += sz;
+  };
+  brotli(preview, npv, cap_pv, "preview plane");
+  Store32((uint32_t)(at - 9), p + 5);  // preview stream + its flags byte
+  p[at++] = flags;                     // cc:825
+  if (!(flags & NO_LOW_BYTES)) brotli(low, npix, cap_pl, "low plane");
+  brotli(high, npix, cap_pl, "high plane");
+  Store32((uint32_t)at, p);
+  p[4] = 0;  // chunk flag: ordinary frame (cc:840)
+  out->assign(p, p + at);
 }
 
 // Image core only (OutputCore, cc:820-828), appended.
@@ -263,7 +277,26 @@ struct WarmUp {
     if (fpvhip_device_count() > 0) {
       int first = 0;
       if (const char* e = getenv("FPV_DEVICES")) first = atoi(e);
-      fpvhip_warmup(first);
+      if (fpvhip_warmup(first)) return;
+      // one frame through the ordinary forward and inverse entry points: the first
+      // launch of a kernel costs 1-3 ms and the first transfer of a megabyte or more in
+      // either direction ~7 ms (the copy engines' queues are created then); the common
+      // kernel variants (little-endian input with a low plane) are the ones this frame takes
+      const uint32_t wx = 1024, wy = 1024;
+      if (fpvhip_ctx* c = fpvhip_create(first, wx, wy, 4, 0, 1, 1)) {
+        std::vector<uint16_t> img((size_t)wx * wy, 0x0123);
+        for (size_t i = 0; i < img.size(); i++) img[i] = (uint16_t)((i * 37) & 0xfff);
+        const uint8_t *h, *l, *pv, *fl;
+        const uint16_t* px;
+        if (fpvhip_set_delta_raw(c, img.data()) == 0) {
+          memcpy(fpvhip_stage_in(c, 0, 0), img.data(), img.size() * 2);
+          if (fpvhip_predict_submit(c, 0, 1, 1) == 0 && fpvhip_predict_wait(c, 0, &h, &l, &pv, &fl) == 0) {
+            const uint8_t f = fl[0] | 2;  // through the speculative inverse as well
+            if (fpvhip_inverse_submit(c, 0, 1, &f) == 0) fpvhip_inverse_wait(c, 0, &px);
+          }
+        }
+        fpvhip_destroy(c);
+      }
     }
   }
 } g_warm_up;
@@ -331,6 +364,9 @@ struct Encoder::Impl {
   std::deque<Batch*> gpu_q;                   // submitted, waiting for the GPU
   std::deque<Task> work_q;                    // Brotli tasks
   std::deque<Task> copy_q;                    // staging copies (served first)
+  struct Prep { int dev; uint32_t slot; };
+  std::deque<Prep> prep_q;                    // slots to allocate ahead of need (served before everything)
+  std::vector<std::vector<char>> slot_prepared;  // [dev][slot]: allocation done or queued
   std::deque<Batch*> emit_q;                  // submission order
   size_t inflight = 0;                        // accepted, not yet emitted
   size_t next_id = 0;
@@ -342,8 +378,10 @@ struct Encoder::Impl {
   std::vector<std::thread> workers;
 
   // Stage statistics (FPV_STATS=1: one stderr line from Finish).  Times in ns.
-  const bool stats = getenv("FPV_STATS") != nullptr;
-  std::atomic<uint64_t> st_brotli_ns{0}, st_copy_ns{0}, st_gpu_wait_ns{0}, st_gpu_us{0}, st_batches{0};
+  const bool print_stats = getenv("FPV_STATS") != nullptr;
+  const bool stats = true;  // a handful of clock reads per frame
+  std::atomic<uint64_t> st_brotli_ns{0}, st_copy_ns{0}, st_gpu_wait_ns{0}, st_gpu_us{0}, st_batches{0}, st_bytes_up{0}, st_bytes_down{0};
+  double last_stats[10] = {};  // filled by Finish (Encoder::LastStats)
   std::chrono::steady_clock::time_point st_t0;
   static uint64_t NowNs() {
     return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(
@@ -372,18 +410,38 @@ struct Encoder::Impl {
     if (rc != 0) Fatal(what, fpvhip_last_error(c));
   }
 
-  // --- producer side (caller thread, m held) ---
-  void SubmitLocked(Batch* b) {
+  // Hands a complete batch to the GPU.  Called WITHOUT the pipeline lock (the call
+  // enqueues copies and launches: the Brotli workers must not queue behind it); the
+  // batch is closed and fully staged, so nothing else touches it meanwhile, and only
+  // one thread ever gets `true` from CloseLocked / the last staging copy for it.
+  void Submit(Batch* b) {
     CheckHip(fpvhip_predict_submit(ctxs[b->dev], b->slot, b->n, 1), ctxs[b->dev],
              "fpvhip_predict_submit");
+    st_bytes_up += (uint64_t)b->n * npix * 2;
+    st_bytes_down += (uint64_t)b->n * (npix * (shift == 8 ? 1 : 2) + npv + 1);
+    std::lock_guard<std::mutex> l(m);
     gpu_q.push_back(b);
     cv_dispatch.notify_one();
   }
 
-  // Closes a batch: it is submitted as soon as all of its frames are staged.
-  void CloseLocked(Batch* b) {
+  // Closes a batch (m held).  Returns true when all of its frames are staged already:
+  // the caller then submits it after dropping the lock.  Otherwise the worker that
+  // finishes the last staging copy does.
+  bool CloseLocked(Batch* b) {
     b->closed = true;
-    if (b->copied == b->n) SubmitLocked(b);
+    return b->copied == b->n;
+  }
+
+  // Queues the allocation of up to `count` slots of device d that nobody has asked for yet
+  // (m held).  Workers allocate different slots side by side.
+  void QueuePrepLocked(size_t d, int count) {
+    for (uint32_t s2 = 0; s2 < slots_per_dev && count > 0; s2++)
+      if (!slot_prepared[d][s2]) {
+        slot_prepared[d][s2] = 1;
+        prep_q.push_back(Prep{(int)d, s2});
+        cv_work.notify_one();
+        count--;
+      }
   }
 
   Batch* OpenBatchLocked(std::unique_lock<std::mutex>& l) {
@@ -394,6 +452,11 @@ struct Encoder::Impl {
           if (!slot_busy[d][s]) {
             slot_busy[d][s] = 1;
             next_dev = (d + 1) % devices.size();  // batch b -> GPU b mod G
+            // The staging memory of a slot is allocated when it is first needed (a few
+            // ms).  Have a worker prepare the slot the NEXT batch of this device will
+            // take while this one is being filled, so that the producer never waits.
+            slot_prepared[d][s] = 1;
+            QueuePrepLocked(d, 2);
             Batch* b = new Batch();
             b->dev = (int)d;
             b->slot = s;
@@ -426,7 +489,11 @@ struct Encoder::Impl {
             std::chrono::steady_clock::now() - cur_touched > std::chrono::milliseconds(2)) {
           Batch* b = cur;
           cur = nullptr;
-          CloseLocked(b);
+          if (CloseLocked(b)) {
+            l.unlock();
+            Submit(b);
+            l.lock();
+          }
         }
         continue;
       }
@@ -492,7 +559,15 @@ struct Encoder::Impl {
   void WorkLoop() {
     std::unique_lock<std::mutex> l(m);
     for (;;) {
-      cv_work.wait(l, [this] { return stop || !work_q.empty() || !copy_q.empty(); });
+      cv_work.wait(l, [this] { return stop || !work_q.empty() || !copy_q.empty() || !prep_q.empty(); });
+      if (!prep_q.empty()) {
+        const Prep pr = prep_q.front();
+        prep_q.pop_front();
+        l.unlock();
+        fpvhip_prepare_slot(ctxs[pr.dev], pr.slot);  // a failure surfaces when the slot is used
+        l.lock();
+        continue;
+      }
       if (!copy_q.empty()) {  // staging copy: the frame stays valid until its callback (h:197-201)
         Task t = copy_q.front();
         copy_q.pop_front();
@@ -502,7 +577,11 @@ struct Encoder::Impl {
         if (stats) st_copy_ns += NowNs() - tc;
         l.lock();
         t.b->copied++;
-        if (t.b->closed && t.b->copied == t.b->n) SubmitLocked(t.b);
+        if (t.b->closed && t.b->copied == t.b->n) {
+          l.unlock();
+          Submit(t.b);
+          l.lock();
+        }
         continue;
       }
       if (work_q.empty()) {
@@ -559,6 +638,12 @@ Encoder::~Encoder() {
 
 size_t Encoder::MaxQueued() const { return impl_->max_queued; }
 
+size_t Encoder::LastStats(double* out, size_t n) const {
+  const size_t k = std::min<size_t>(n, 10);
+  for (size_t i = 0; i < k; i++) out[i] = impl_->last_stats[i];
+  return k;
+}
+
 void Encoder::Init(const uint16_t* delta_frame, size_t xsize, size_t ysize,
                    Callback callback, void* payload) {
   Impl& s = *impl_;
@@ -585,6 +670,8 @@ void Encoder::Init(const uint16_t* delta_frame, size_t xsize, size_t ysize,
     if (fpvhip_set_delta_raw(c, delta_frame)) Fatal("fpvhip_set_delta_raw", fpvhip_last_error(c));
   }
   s.slot_busy.assign(s.devices.size(), std::vector<char>(s.slots_per_dev, 0));
+  s.slot_prepared.assign(s.devices.size(), std::vector<char>(s.slots_per_dev, 0));
+  for (auto& v : s.slot_prepared) v[0] = 1;  // slot 0 comes with the context
   const double t_ctx = now();
 
   // The delta frame itself: predicted WITHOUT a delta frame (cc:1099-1100),
@@ -594,21 +681,46 @@ void Encoder::Init(const uint16_t* delta_frame, size_t xsize, size_t ysize,
   s.CheckHip(fpvhip_predict_submit(c0, 0, 1, 0), c0, "fpvhip_predict_submit");
   const uint8_t *high, *low, *pv, *flags;
   s.CheckHip(fpvhip_predict_wait(c0, 0, &high, &low, &pv, &flags), c0, "fpvhip_predict_wait");
+  const double t_pred = now();
   std::vector<uint8_t> out;
   out.reserve(s.npix + 64);
   Append32((uint32_t)xsize, &out);
   Append32((uint32_t)ysize, &out);
   Append32(0, &out);
   out.push_back(1);
-  AppendCore(high, low, flags[0], s.npix, &out);
+  s.initialized = true;
+  if (s.num_threads > 0) {
+    s.StartThreads();  // the workers spawn while the delta frame is compressed ...
+    std::lock_guard<std::mutex> l(s.m);
+    for (size_t d = 0; d < s.devices.size(); d++) s.QueuePrepLocked(d, 2);  // ... and prepare the next slots
+  }
+  {
+    // image core (cc:820-828): flags | [brotli(low)] | brotli(high); the two planes are
+    // compressed side by side when worker threads are wanted at all
+    const uint8_t f = flags[0];
+    std::vector<uint8_t> low_stream;
+    std::thread low_thread;
+    const bool with_low = !(f & NO_LOW_BYTES);
+    if (with_low && s.num_threads > 0)
+      low_thread = std::thread([&] { if (!BrotliAppend(low, s.npix, &low_stream)) Fatal("Brotli", "low plane"); });
+    out.push_back(f);
+    std::vector<uint8_t> high_stream;
+    if (low_thread.joinable()) {
+      if (!BrotliAppend(high, s.npix, &high_stream)) Fatal("Brotli", "high plane");
+      low_thread.join();
+      out.insert(out.end(), low_stream.begin(), low_stream.end());
+      out.insert(out.end(), high_stream.begin(), high_stream.end());
+    } else {
+      if (with_low && !BrotliAppend(low, s.npix, &out)) Fatal("Brotli", "low plane");
+      if (!BrotliAppend(high, s.npix, &out)) Fatal("Brotli", "high plane");
+    }
+  }
   Store32((uint32_t)(out.size() - 8), out.data() + 8);
   s.bytes_written = out.size();
-  s.initialized = true;
-  if (s.num_threads > 0) s.StartThreads();
   if (timing)
-    fprintf(stderr, "fpv-mi355x: Init: contexts + delta upload %.1f ms, delta frame predict + Brotli %.1f ms "
+    fprintf(stderr, "fpv-mi355x: Init: contexts + delta upload %.1f ms, delta frame predict %.1f ms, threads + Brotli %.1f ms "
                     "(batch %zu, %u slots, %zu device(s))\n",
-            t_ctx - t_start, now() - t_ctx, s.batch, s.slots_per_dev, s.devices.size());
+            t_ctx - t_start, t_pred - t_ctx, now() - t_pred, s.batch, s.slots_per_dev, s.devices.size());
   callback(out.data(), out.size(), payload);
 }
 
@@ -648,7 +760,11 @@ void Encoder::CompressFrame(const uint16_t* img, Callback callback, void* payloa
   // because the frames of a partial batch would otherwise never complete.
   if (b->n == s.batch || s.inflight >= s.max_queued) {
     s.cur = nullptr;
-    s.CloseLocked(b);
+    if (s.CloseLocked(b)) {
+      l.unlock();
+      s.Submit(b);
+      l.lock();
+    }
   }
   s.cv_producer.wait(l, [&s] { return s.inflight < s.max_queued; });  // cc:1150-1156
 }
@@ -663,7 +779,11 @@ void Encoder::Finish(Callback callback, void* payload) {
       if (s.cur) {
         Impl::Batch* b = s.cur;
         s.cur = nullptr;
-        s.CloseLocked(b);  // never empty: a batch is opened by its first frame
+        if (s.CloseLocked(b)) {  // never empty: a batch is opened by its first frame
+          l.unlock();
+          s.Submit(b);
+          l.lock();
+        }
       }
       s.cv_producer.wait(l, [&s] { return s.inflight == 0 && s.emit_q.empty(); });
     }
@@ -673,21 +793,28 @@ void Encoder::Finish(Callback callback, void* payload) {
   s.ReleaseContexts();
   // frame index (cc:1185-1197)
   const size_t n = s.offsets.size();
-  if (s.stats && n > 0 && s.num_threads > 0) {
-    // Stage totals of the pipeline: the GPU stage is what the slots' streams spent
-    // (H2D + kernels + D2H, HIP events), Brotli and staging copies are summed over
-    // the worker threads.  With perfect overlap the wall time equals the largest of
-    // gpu / devices, (brotli + copies) / threads.
+  if (n > 0 && s.num_threads > 0) {
+    // Stage totals of the pipeline.  Brotli and staging copies are summed over the worker
+    // threads; the GPU side is given as the mean latency of a batch (first transfer in ->
+    // last transfer out, HIP events: batches of different slots overlap on the transfer
+    // streams, so their latencies do not add up to a busy time) and as the bytes moved each
+    // way per second of wall time.  With perfect overlap the wall time equals
+    // (brotli + copies) / threads, the largest stage by far.
     const double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - s.st_t0).count();
     const double gpu = s.st_gpu_us / 1e3, brotli = s.st_brotli_ns / 1e6, copy = s.st_copy_ns / 1e6;
-    const double host_stage = (brotli + copy) / (double)s.num_threads, gpu_stage = gpu / (double)s.devices.size();
-    const double bound = std::max(host_stage, gpu_stage);
-    fprintf(stderr,
-            "fpv-mi355x: stats: %zu frames %zux%zu, wall %.1f ms (%.1f fps); GPU stage (H2D+kernels+D2H) %.1f ms in %llu "
-            "batches = %.3f ms/frame; Brotli %.1f ms + staging copies %.1f ms over %zu threads = %.3f ms/frame/thread; "
-            "dispatcher blocked on the GPU %.1f ms; overlap: max(stage)/wall = %.2f, sum(stages)/wall = %.2f\n",
-            n, s.xs, s.ys, wall, n / wall * 1e3, gpu, (unsigned long long)s.st_batches.load(), gpu / n, brotli, copy,
-            s.num_threads, (brotli + copy) / n, s.st_gpu_wait_ns / 1e6, bound / wall, (host_stage + gpu_stage) / wall);
+    const double host_stage = (brotli + copy) / (double)s.num_threads;
+    const double batches = (double)std::max<uint64_t>(1, s.st_batches.load());
+    double* o = s.last_stats;
+    o[0] = (double)n; o[1] = wall; o[2] = brotli; o[3] = copy; o[4] = gpu / batches; o[5] = batches;
+    o[6] = s.st_bytes_up / (wall * 1e6); o[7] = s.st_bytes_down / (wall * 1e6);  // GB/s
+    o[8] = host_stage / wall; o[9] = s.st_gpu_wait_ns / 1e6;
+    if (s.print_stats)
+      fprintf(stderr,
+              "fpv-mi355x: stats: %zu frames %zux%zu, wall %.1f ms (%.1f fps); Brotli %.1f ms + staging copies %.1f ms over %zu "
+              "threads = %.3f ms/frame/thread; GPU: %.0f batches, mean latency %.2f ms (copy in + kernels + copy out), "
+              "%.1f GB/s in, %.1f GB/s out over the wall time; dispatcher blocked on the GPU %.1f ms; overlap: host stage / wall = %.2f\n",
+              n, s.xs, s.ys, wall, n / wall * 1e3, brotli, copy, s.num_threads, (brotli + copy) / n, batches, gpu / batches,
+              o[6], o[7], s.st_gpu_wait_ns / 1e6, host_stage / wall);
   }
   std::vector<uint8_t> out(5 + 8 * n + 8);
   Store32((uint32_t)out.size(), out.data());

@@ -61,6 +61,9 @@ void carve_fwd_workspace(const Geom& g, uint32_t nframes, void* base,
                          FwdWorkspace* ws);
 hipError_t init_fwd_workspace(const FwdWorkspace& ws, hipStream_t s);
 
+// Per-device one-time set-up of the kernels (function attributes); idempotent, thread-safe.
+void prepare_kernels();
+
 // Plain device copy (bench: measured HBM ceiling).
 hipError_t launch_copy(const void* src, void* dst, size_t bytes, hipStream_t s);
 

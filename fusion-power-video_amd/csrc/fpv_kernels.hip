@@ -276,10 +276,6 @@ __device__ __forceinline__ void st_agent8(uint8_t* p, uint8_t v) {
 __device__ __forceinline__ uint32_t ld_agent8(const uint8_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void st_agent128(void* p, uint4 v) {
-  st_agent64(p, (uint64_t)v.x | ((uint64_t)v.y << 32));
-  st_agent64(static_cast<uint8_t*>(p) + 8, (uint64_t)v.z | ((uint64_t)v.w << 32));
-}
 __device__ __forceinline__ uint4 ld_agent128(const void* p) {
   const uint64_t a = ld_agent64(p), b = ld_agent64(static_cast<const uint8_t*>(p) + 8);
   return make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
@@ -2270,6 +2266,36 @@ hipError_t launch_split_decoded(const Geom& g, const uint16_t* d_img,
   return hipGetLastError();
 }
 
+// Function attributes (dynamic LDS above 64 KiB) of every kernel that needs them, once per
+// device.  Called by the launch functions and by fpvhip_warmup (so that a first session
+// does not pay for it).
+void prepare_kernels() {
+  static std::mutex attr_m;
+  static uint64_t attr_done = 0;
+  once_per_device(attr_m, attr_done, [] {  // wide frames need more than 64 KiB of LDS per wave
+#define FPV_SF(K, W, F, L) reinterpret_cast<const void*>(&K<W, F, L>)
+    const void* sf[16] = {
+        FPV_SF(k_stream, true, true, true),        FPV_SF(k_stream, true, true, false),
+        FPV_SF(k_stream, true, false, true),       FPV_SF(k_stream, true, false, false),
+        FPV_SF(k_stream, false, true, true),       FPV_SF(k_stream, false, true, false),
+        FPV_SF(k_stream, false, false, true),      FPV_SF(k_stream, false, false, false),
+        FPV_SF(k_redo_stream, true, true, true),   FPV_SF(k_redo_stream, true, true, false),
+        FPV_SF(k_redo_stream, true, false, true),  FPV_SF(k_redo_stream, true, false, false),
+        FPV_SF(k_redo_stream, false, true, true),  FPV_SF(k_redo_stream, false, true, false),
+        FPV_SF(k_redo_stream, false, false, true), FPV_SF(k_redo_stream, false, false, false)};
+#undef FPV_SF
+    for (const void* f : sf)
+      hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxWaveLds);
+  
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inverse<true>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inverse<false>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inverse_fast),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    });
+}
+
 template <bool SWAP>
 static hipError_t predict_impl(const Geom& g, const uint16_t* d_frames,
                                uint32_t nframes, const uint8_t* d_dhigh,
@@ -2331,23 +2357,7 @@ hipError_t launch_predict(const Geom& g, const uint16_t* d_frames,
                           const uint8_t* d_dlow, FwdWorkspace& ws,
                           uint8_t* d_high, uint8_t* d_low, uint8_t* d_preview,
                           uint8_t* d_flags, hipStream_t s, hipEvent_t* ev) {
-  static std::mutex attr_m;
-  static uint64_t attr_done = 0;
-  once_per_device(attr_m, attr_done, [] {  // wide frames need more than 64 KiB of LDS per wave
-#define FPV_SF(K, W, F, L) reinterpret_cast<const void*>(&K<W, F, L>)
-    const void* sf[16] = {
-        FPV_SF(k_stream, true, true, true),        FPV_SF(k_stream, true, true, false),
-        FPV_SF(k_stream, true, false, true),       FPV_SF(k_stream, true, false, false),
-        FPV_SF(k_stream, false, true, true),       FPV_SF(k_stream, false, true, false),
-        FPV_SF(k_stream, false, false, true),      FPV_SF(k_stream, false, false, false),
-        FPV_SF(k_redo_stream, true, true, true),   FPV_SF(k_redo_stream, true, true, false),
-        FPV_SF(k_redo_stream, true, false, true),  FPV_SF(k_redo_stream, true, false, false),
-        FPV_SF(k_redo_stream, false, true, true),  FPV_SF(k_redo_stream, false, true, false),
-        FPV_SF(k_redo_stream, false, false, true), FPV_SF(k_redo_stream, false, false, false)};
-#undef FPV_SF
-    for (const void* f : sf)
-      hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxWaveLds);
-  });
+  prepare_kernels();
   if (g.swap)
     return predict_impl<true>(g, d_frames, nframes, d_dhigh, d_dlow, ws, d_high,
                               d_low, d_preview, d_flags, s, ev);
@@ -2360,16 +2370,7 @@ hipError_t launch_inverse(const Geom& g, const uint8_t* d_high,
                           const uint8_t* d_dlow, const uint8_t* d_flags,
                           uint32_t nframes, uint16_t* d_frames, hipStream_t s,
                           uint32_t* d_diag) {
-  static std::mutex attr_m;
-  static uint64_t attr_done = 0;
-  once_per_device(attr_m, attr_done, [] {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inverse<true>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inverse<false>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inverse_fast),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-  });
+  prepare_kernels();
   // FPV_INVERSE = auto (default) | trio | spec | fast | slow selects the kernel (tests, A/B timing).
   // auto: three waves per frame (shorter serial path per frame) while every frame's
   // chain wave can have a SIMD to itself most of the time, one wave per frame (less

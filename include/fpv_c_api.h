@@ -24,6 +24,17 @@ void fpvc_encoder_compress_frame(void *enc, const uint16_t *img, fpvc_write_fn c
                                  void *payload);
 void fpvc_encoder_finish(void *enc, fpvc_write_fn cb, void *payload);
 void fpvc_encoder_free(void *enc);
+/* Encoder::LastStats (extension): stage statistics after Finish; see fusion_power_video.h. */
+size_t fpvc_encoder_stats(const void *enc, double *out, size_t n);
+/*
+ * Benchmark helper: Encoder construction -> Finish over `total` frames cycling through
+ * `distinct` resident ones (frame 0 doubles as the delta frame, as encode.cc does), timed
+ * as benchmark.cc:153-180 times it, every chunk copied away by the callback.  Returns
+ * the seconds; *bytes_out = stream size; stats as fpvc_encoder_stats.
+ */
+double fpvc_bench_encode(const uint16_t *frames, size_t distinct, size_t total, size_t xs,
+                         size_t ys, int shift, int big_endian, size_t num_threads,
+                         size_t *bytes_out, double *stats, size_t nstats);
 
 /*
  * Whole-stream helpers.  encode: Init(delta) + CompressFrame x n + Finish into

@@ -101,6 +101,13 @@ int fpvhip_split_frame(fpvhip_ctx *ctx, const uint16_t *img, uint8_t *high,
 
 /* ---- forward predictor, host-staged (Encoder pipeline) ------------------ */
 
+/*
+ * Allocate the staging memory of `slot` now (it is otherwise allocated when the slot is
+ * first touched): lets a pipeline prepare its next slot on another thread while the
+ * current one is being filled.  Thread-safe; a no-op for a slot that exists.
+ */
+int fpvhip_prepare_slot(fpvhip_ctx *ctx, uint32_t slot);
+
 /* Pinned host buffer for input frame k of `slot` (npix uint16). */
 uint16_t *fpvhip_stage_in(fpvhip_ctx *ctx, uint32_t slot, uint32_t k);
 /*

@@ -185,6 +185,13 @@ class Encoder {
   void Finish(Callback callback, void* payload);
   // Upper bound of frames in flight; usable right after construction.
   size_t MaxQueued() const;
+  // Extension (not in the upstream header): stage statistics of the session, valid after
+  // Finish.  out[0] frames, [1] wall ms since Init, [2] Brotli ms and [3] staging-copy ms
+  // summed over the workers, [4] mean GPU batch latency ms (copy in + kernels + copy out),
+  // [5] batches, [6] GB/s copied in and [7] out over the wall time, [8] host stage
+  // (Brotli + copies, per thread) / wall, [9] ms the dispatcher waited for the GPU.
+  // Returns the number of values written (at most n).
+  size_t LastStats(double* out, size_t n) const;
 
  private:
   struct Impl;

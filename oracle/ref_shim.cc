@@ -10,6 +10,7 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <chrono>
 #include <vector>
 
 #include "fusion_power_video.h"  // from /root/reference via -I
@@ -69,6 +70,29 @@ size_t ref_encode_stream(const uint16_t* frames, size_t nframes,
   if (bytes.size() > cap) return 0;
   memcpy(out, bytes.data(), bytes.size());
   return bytes.size();
+}
+
+// The reference Encoder timed as the upstream benchmark times it (benchmark.cc:153-180:
+// construction -> Finish, every chunk copied away by the callback) over `total` frames
+// cycling through `distinct` resident ones.  Returns the seconds.
+double ref_bench_encode(const uint16_t* frames, size_t distinct, size_t total, size_t xs, size_t ys,
+                        int shift, int big_endian, size_t num_threads, size_t* bytes_out) {
+  struct Out { std::vector<uint8_t> last; size_t bytes; } out = {{}, 0};
+  auto cb = [](const uint8_t* d, size_t n, void* p) {
+    Out* o = static_cast<Out*>(p);
+    o->last.assign(d, d + n);
+    o->bytes += n;
+  };
+  const auto t0 = std::chrono::steady_clock::now();
+  {
+    fpvc::Encoder enc(num_threads, shift, big_endian != 0);
+    enc.Init(frames, xs, ys, cb, &out);
+    for (size_t i = 0; i < total; i++) enc.CompressFrame(frames + (i % distinct) * xs * ys, cb, &out);
+    enc.Finish(cb, &out);
+  }
+  const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (bytes_out) *bytes_out = out.bytes;
+  return dt;
 }
 
 // RandomAccessDecoder over a whole stream; returns frame count or -1.

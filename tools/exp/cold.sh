@@ -1,8 +1,15 @@
-python - <<'PY'
+#!/bin/bash
+set -u
+cd "$(dirname "$0")/../.."
+W=$(mktemp -d /tmp/fpv_cold.XXXX); trap 'rm -rf "$W"' EXIT
+python - "$W" <<'PY'
 import sys, importlib
-sys.path.insert(0,'.')
+sys.path.insert(0, '.')
 from __graft_entry__ import load_package
-load_package(); synth=importlib.import_module('fpv_amd.synth')
-synth.plasma_frames(100,1280,800,bits=12).tofile('/tmp/p100.raw')
+load_package()
+synth = importlib.import_module('fpv_amd.synth')
+synth.plasma_frames(100, 1280, 800, bits=12).tofile(sys.argv[1] + '/plasma100.raw')
 PY
-for t in 8 64; do FPV_TIMING=1 ./build/bin/fpv_benchmark /tmp/p100.raw 1280 800 0 4 100 $t 2>&1 | grep -E "Init|encode"; done
+for t in 8 32 64; do echo "== threads $t"; FPV_TIMING=1 FPV_STATS=1 timeout 90 ./build/bin/fpv_benchmark $W/plasma100.raw 1280 800 0 4 100 $t 2>&1 | grep -E "fpv-mi355x|encode"; done
+echo "== pcie with hipHostMalloc"; FPV_NO_HOST_REGISTER=1 timeout 120 python tools/pcie_rate.py 2>&1 | grep batch
+echo "== pcie with register"; timeout 120 python tools/pcie_rate.py 2>&1 | grep batch

@@ -92,6 +92,62 @@ int main() {
     printf("unregister: %.3f ms each\n", (now() - t0) / k);
     free(p);
   }
+  for (int kind = 0; kind < 2; kind++) {  // FIRST copies out of / into fresh staging memory
+    const size_t n = (size_t)64 << 20;
+    void* h = nullptr;
+    if (kind == 0) { CK(hipHostMalloc(&h, n, hipHostMallocDefault)); }
+    else {
+      h = mmap(nullptr, n, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+      madvise(h, n, MADV_HUGEPAGE); touch_parallel((char*)h, n, 1);
+      CK(hipHostRegister(h, n, hipHostRegisterDefault));
+    }
+    void* dnew; CK(hipMalloc(&dnew, n));
+    double t[5];
+    t0 = now(); CK(hipMemcpyAsync(dnew, h, 2 << 20, hipMemcpyHostToDevice, s)); CK(hipStreamSynchronize(s)); t[0] = now() - t0;
+    t0 = now(); CK(hipMemcpyAsync(dnew, h, 2 << 20, hipMemcpyHostToDevice, s)); CK(hipStreamSynchronize(s)); t[1] = now() - t0;
+    t0 = now(); CK(hipMemcpyAsync(dnew, h, n, hipMemcpyHostToDevice, s)); CK(hipStreamSynchronize(s)); t[2] = now() - t0;
+    t0 = now(); CK(hipMemcpyAsync(h, dnew, n, hipMemcpyDeviceToHost, s)); CK(hipStreamSynchronize(s)); t[3] = now() - t0;
+    t0 = now(); CK(hipMemcpyAsync(h, dnew, n, hipMemcpyDeviceToHost, s)); CK(hipStreamSynchronize(s)); t[4] = now() - t0;
+    printf("fresh %s 64 MB + fresh device buffer: first 2 MB H2D %.3f ms, again %.3f ms, 64 MB H2D %.3f ms, first 64 MB D2H %.3f ms, again %.3f ms\n",
+           kind ? "mmap+register" : "hipHostMalloc", t[0], t[1], t[2], t[3], t[4]);
+    std::vector<char> pg((size_t)4 << 20, 1);
+    t0 = now(); CK(hipMemcpy(dnew, pg.data(), 2 << 20, hipMemcpyHostToDevice)); t[0] = now() - t0;
+    t0 = now(); CK(hipMemcpy(dnew, pg.data(), 2 << 20, hipMemcpyHostToDevice)); t[1] = now() - t0;
+    printf("   pageable 2 MB hipMemcpy: first %.3f ms, again %.3f ms\n", t[0], t[1]);
+  }
+  {  // full duplex: H2D on one stream while D2H runs on another
+    const size_t n = (size_t)64 << 20;
+    void *h1, *h2, *d1, *d2;
+    CK(hipHostMalloc(&h1, n, hipHostMallocDefault)); CK(hipHostMalloc(&h2, n, hipHostMallocDefault));
+    CK(hipMalloc(&d1, n)); CK(hipMalloc(&d2, n));
+    hipStream_t s2; CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+    CK(hipMemcpyAsync(d1, h1, n, hipMemcpyHostToDevice, s)); CK(hipMemcpyAsync(h2, d2, n, hipMemcpyDeviceToHost, s2));
+    CK(hipStreamSynchronize(s)); CK(hipStreamSynchronize(s2));
+    t0 = now();
+    for (int i = 0; i < 8; i++) { CK(hipMemcpyAsync(d1, h1, n, hipMemcpyHostToDevice, s)); CK(hipMemcpyAsync(h2, d2, n, hipMemcpyDeviceToHost, s2)); }
+    CK(hipStreamSynchronize(s)); CK(hipStreamSynchronize(s2));
+    double dt = now() - t0;
+    printf("duplex: 8 x 64 MB each way on two streams: %.2f ms -> %.1f GB/s each way\n", dt, 8.0 * n / (dt * 1e6));
+    t0 = now();
+    for (int i = 0; i < 8; i++) { CK(hipMemcpyAsync(d1, h1, n, hipMemcpyHostToDevice, s)); CK(hipMemcpyAsync(h2, d2, n, hipMemcpyDeviceToHost, s)); }
+    CK(hipStreamSynchronize(s));
+    dt = now() - t0;
+    printf("same stream, alternating directions: %.2f ms -> %.1f GB/s each way\n", dt, 8.0 * n / (dt * 1e6));
+    // three streams, each doing H2D then D2H of its own buffers (the slots' pattern)
+    hipStream_t st[4]; void *hh[4], *dd[4];
+    for (int i = 0; i < 4; i++) { CK(hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking)); CK(hipHostMalloc(&hh[i], n, hipHostMallocDefault)); CK(hipMalloc(&dd[i], n)); }
+    for (int nst : {2, 4}) {
+      t0 = now();
+      for (int r = 0; r < 6; r++)
+        for (int i = 0; i < nst; i++) {
+          CK(hipMemcpyAsync(dd[i], hh[i], n / 2, hipMemcpyHostToDevice, st[i]));
+          CK(hipMemcpyAsync((char*)hh[i] + n / 2, (char*)dd[i] + n / 2, n / 2, hipMemcpyDeviceToHost, st[i]));
+        }
+      for (int i = 0; i < nst; i++) CK(hipStreamSynchronize(st[i]));
+      dt = now() - t0;
+      printf("%d streams x (32 MB up, 32 MB down) x 6: %.2f ms -> %.1f GB/s each way\n", nst, dt, 6.0 * nst * (n / 2) / (dt * 1e6));
+    }
+  }
   {  // concurrent hipHostMalloc from 4 threads
     t0 = now();
     std::vector<std::thread> t; void* hp[4];

@@ -41,8 +41,13 @@ $(LIBDIR)/libfpv_amd.so: $(HOST_SRC) $(HOST_HDR) $(LIBDIR)/libfpvhip.so
 	$(CXX) $(CXXFLAGS) -shared $(HOST_SRC) -L$(LIBDIR) -lfpvhip $(BROTLI) \
 	    -Wl,-rpath,'$$ORIGIN' -o $@
 
-# Our own CLI tools (written from scratch; usable on the GPU box).
-tools: $(BINDIR)/fpv_encode $(BINDIR)/fpv_decode $(BINDIR)/fpv_benchmark
+# Our own CLI tools (written from scratch; usable on the GPU box) and the native test driver
+# of the BASELINE configurations at their stated frame counts.
+tools: $(BINDIR)/fpv_encode $(BINDIR)/fpv_decode $(BINDIR)/fpv_benchmark $(BINDIR)/configs_driver
+$(BINDIR)/configs_driver: tests/configs_driver.cc $(LIBDIR)/libfpv_amd.so
+	@mkdir -p $(BINDIR)
+	$(CXX) $(CXXFLAGS) $< -L$(LIBDIR) -lfpv_amd -lfpvhip \
+	    -Wl,-rpath,'$$ORIGIN/../../$(LIBDIR)' -Wl,-rpath,$(ROCM_LIB) -o $@
 $(BINDIR)/fpv_%: tools/fpv_%.cc $(LIBDIR)/libfpv_amd.so
 	@mkdir -p $(BINDIR)
 	$(CXX) $(CXXFLAGS) $< -L$(LIBDIR) -lfpv_amd -lfpvhip \

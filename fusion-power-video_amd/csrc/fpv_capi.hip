@@ -358,6 +358,30 @@ uint32_t fpvhip_slots(const fpvhip_ctx* c) { return c ? c->nslots : 0; }
 
 int fpvhip_prepare_slot(fpvhip_ctx* c, uint32_t slot) { return check_slot(c, slot); }
 
+size_t fpvhip_staging_bytes(const fpvhip_ctx* c) {
+  size_t b = 0;
+  if (c)
+    for (uint32_t k = 0; k < c->nslots; k++)
+      if (c->slots[k].ready.load(std::memory_order_acquire)) b += c->slots[k].host.bytes;
+  return b;
+}
+
+int fpvhip_trim(fpvhip_ctx* c) {
+  if (!c) return fail(nullptr, "null context");
+  HIPOK(c, hipSetDevice(c->device));
+  for (hipStream_t st : {c->up, c->comp, c->down}) HIPOK(c, hipStreamSynchronize(st));
+  for (uint32_t k = 1; k < c->nslots; k++) {
+    Slot& s = c->slots[k];
+    std::lock_guard<std::mutex> l(s.alloc_m);
+    if (!s.ready.load(std::memory_order_acquire) || s.pending) continue;
+    s.ready.store(false, std::memory_order_release);
+    free_slot(&s);
+    s.done = s.begin = s.up_done = s.k_done = nullptr;
+    s.dev = s.d_ws = nullptr;
+  }
+  return 0;
+}
+
 int fpvhip_set_delta_raw(fpvhip_ctx* c, const uint16_t* delta_raw) {
   if (!c || !delta_raw) return fail(c, "null argument");
   if (!c->g.fwd_ok) return fail(c, "decoder-only context");

@@ -48,15 +48,24 @@ fpvhip_ctx* AcquireEncoderCtx(int device, uint32_t xs, uint32_t ys, int shift,
   return c;
 }
 
+// Idle contexts stay cached for the next session of the same geometry, bounded by count and
+// by the pinned staging memory they hold (FPV_POOL_MB, default 1024): beyond the byte bound
+// idle contexts first give back all slots but one (fpvhip_trim), then the oldest are
+// destroyed.  Whatever a reused context remembers (delta planes, speculation byte) is
+// overwritten by Init / harmless.
 void ReleaseEncoderCtx(fpvhip_ctx* ctx) {
-  std::vector<fpvhip_ctx*> drop;
+  std::vector<fpvhip_ctx*> drop, trim;
+  const size_t cap = EnvSize("FPV_POOL_MB", 1024) << 20;
   {
     std::lock_guard<std::mutex> l(g_pool_m);
-    size_t idle = 0;
+    size_t idle = 0, bytes = 0;
     for (auto& e : g_pool) {
       if (e.ctx == ctx) e.in_use = false;
-      if (!e.in_use) idle++;
+      if (!e.in_use) { idle++; bytes += fpvhip_staging_bytes(e.ctx); }
     }
+    if (bytes > cap)
+      for (auto& e : g_pool)
+        if (!e.in_use) trim.push_back(e.ctx);
     for (size_t i = 0; i < g_pool.size() && idle > kMaxIdle;) {
       if (!g_pool[i].in_use && g_pool[i].ctx != ctx) {
         drop.push_back(g_pool[i].ctx);
@@ -65,6 +74,12 @@ void ReleaseEncoderCtx(fpvhip_ctx* ctx) {
       } else {
         i++;
       }
+    }
+    // trimming happens under the lock: an idle context must not be acquired meanwhile
+    for (fpvhip_ctx* c : trim) {
+      bool gone = false;
+      for (fpvhip_ctx* d : drop) gone |= d == c;
+      if (!gone) fpvhip_trim(c);
     }
   }
   for (fpvhip_ctx* c : drop) fpvhip_destroy(c);
@@ -205,6 +220,11 @@ bool InverseEngine::DecodePlanesBatch(const PlaneStreams* images, size_t n, cons
 bool InverseEngine::RunBatches(size_t n, const Unpacker& unpack, const Sink& sink, size_t threads, int unshift,
                                bool big_endian) {
   if (threads == 0) threads = 1;
+  // One batched request at a time per engine: a request holds the previous batch's slot
+  // while it fills the next one, so two concurrent requests on an engine with two slots
+  // would each end up holding one and waiting for the other's.  Single-image Decode
+  // calls never hold a slot while waiting for another and stay concurrent.
+  std::lock_guard<std::mutex> run_lock(run_m_);
   // Two slots alternate: while the GPU inverts batch g, the host threads
   // Brotli-decode batch g+1 into the other slot.
   struct Flight { int slot = -1; size_t first = 0, count = 0; };
@@ -514,6 +534,7 @@ bool RandomAccessDecoder::DecodeSharded(const size_t* indices, size_t count, voi
         ins.data(), sizes.data(), count,
         [&](size_t i, const uint16_t* px) { memcpy(out[i], px, bytes); }, threads, unshift, big_endian);
   }
+  std::vector<std::shared_ptr<InverseEngine>> engines;  // snapshot: other callers may append meanwhile
   {
     std::lock_guard<std::mutex> l(st.m);
     while (st.more.size() + 1 < shards) {
@@ -521,6 +542,8 @@ bool RandomAccessDecoder::DecodeSharded(const size_t* indices, size_t count, voi
       if (!e || !e->SetDelta(st.delta16.data())) return FPV_FAILURE("no GPU decoder on a further device");
       st.more.push_back(e);
     }
+    engines.push_back(st.engine);
+    for (size_t g = 1; g < shards; g++) engines.push_back(st.more[g - 1]);
   }
   std::vector<char> ok(shards, 0);
   std::vector<std::thread> pool;
@@ -528,7 +551,7 @@ bool RandomAccessDecoder::DecodeSharded(const size_t* indices, size_t count, voi
   for (size_t g = 0; g < shards; g++) {
     pool.emplace_back([&, g] {
       const size_t first = g * per, n = first < count ? std::min(per, count - first) : 0;
-      InverseEngine* e = g == 0 ? st.engine.get() : st.more[g - 1].get();
+      InverseEngine* e = engines[g].get();
       ok[g] = n == 0 || e->DecodeBatch(
                             ins.data() + first, sizes.data() + first, n,
                             [&, first](size_t i, const uint16_t* px) { memcpy(out[first + i], px, bytes); }, th,

@@ -116,6 +116,7 @@ class InverseEngine {
   std::mutex m_;
   std::condition_variable cv_;
   std::vector<char> busy_;
+  std::mutex run_m_;  // serialises batched requests (RunBatches)
 };
 
 }  // namespace internal

@@ -162,11 +162,18 @@ __global__ __launch_bounds__(kThreads) void k_split_decoded(
     uint8_t* __restrict__ low, uint32_t npix) {
   uint32_t i = (blockIdx.x * kThreads + threadIdx.x) * 4;
   if (i >= npix) return;
-  const uint2 v = *reinterpret_cast<const uint2*>(img + i);
-  uint32_t h4, l4;
-  split4<false>(v.x, v.y, 0, &h4, &l4);  // delta >> 8, delta & 0xff (cc:337-338)
-  *reinterpret_cast<uint32_t*>(high + i) = h4;
-  *reinterpret_cast<uint32_t*>(low + i) = l4;
+  if (i + 4 <= npix) {
+    const uint2 v = *reinterpret_cast<const uint2*>(img + i);
+    uint32_t h4, l4;
+    split4<false>(v.x, v.y, 0, &h4, &l4);  // delta >> 8, delta & 0xff (cc:337-338)
+    *reinterpret_cast<uint32_t*>(high + i) = h4;
+    *reinterpret_cast<uint32_t*>(low + i) = l4;
+  } else {  // the last 1..3 pixels of a plane whose size is not a multiple of 4 (odd decoder geometries)
+    for (uint32_t k = i; k < npix; k++) {
+      high[k] = (uint8_t)(img[k] >> 8);
+      low[k] = (uint8_t)(img[k] & 0xff);
+    }
+  }
 }
 
 // UnextractFrame (cc:850-862) on the device, in place: decoded pixels -> the raw file
@@ -2261,7 +2268,7 @@ hipError_t launch_unextract(uint16_t* d_px, size_t npix_total, int shift, int bi
 
 hipError_t launch_split_decoded(const Geom& g, const uint16_t* d_img,
                                 uint8_t* d_high, uint8_t* d_low, hipStream_t s) {
-  dim3 grid((g.npix / 4 + kThreads - 1) / kThreads);
+  dim3 grid(((g.npix + 3) / 4 + kThreads - 1) / kThreads);  // a thread per started group of 4 pixels
   k_split_decoded<<<grid, kThreads, 0, s>>>(d_img, d_high, d_low, g.npix);
   return hipGetLastError();
 }

@@ -108,6 +108,13 @@ int fpvhip_split_frame(fpvhip_ctx *ctx, const uint16_t *img, uint8_t *high,
  */
 int fpvhip_prepare_slot(fpvhip_ctx *ctx, uint32_t slot);
 
+/* Bytes of pinned host staging memory the context holds right now (the same amount again
+ * lives on the device). */
+size_t fpvhip_staging_bytes(const fpvhip_ctx *ctx);
+/* Give back every slot but the first (none may be in flight); they are allocated again when
+ * next touched.  For caches of idle contexts. */
+int fpvhip_trim(fpvhip_ctx *ctx);
+
 /* Pinned host buffer for input frame k of `slot` (npix uint16). */
 uint16_t *fpvhip_stage_in(fpvhip_ctx *ctx, uint32_t slot, uint32_t k);
 /*

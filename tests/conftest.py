@@ -15,6 +15,17 @@ def pytest_configure(config):
     _build_if_missing()
 
 
+def pytest_collection_modifyitems(config, items):
+    """`gpu` tests need a device: without /dev/kfd they are skipped instead of failing (a plain
+    `pytest` on a box without a GPU).  Nothing here initialises HIP in the pytest process."""
+    if os.path.exists("/dev/kfd") or os.environ.get("FPV_FORCE_GPU_TESTS"):
+        return
+    skip = pytest.mark.skip(reason="no GPU on this machine (/dev/kfd absent)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 def _build_if_missing():
     """The suites need the in-tree libraries (product + CPU test shim).  They are built
     by `make` / __graft_entry__.build(); if someone runs pytest on a fresh checkout, build

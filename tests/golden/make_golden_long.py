@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE: adds the long-stream entries to tests/golden/manifest.json by running
+the REAL reference (oracle/_ref/encode = the upstream encode.cc + library compiled here by
+oracle/Makefile) on the cycled synthetic frames.  Only data (hashes, sizes) is stored.
+
+  config 1 at its stated size: 1000 frames 1280x800 12-bit plasma, 64 distinct frames cycled."""
+import hashlib, importlib, json, os, subprocess, sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package  # noqa: E402
+load_package()
+synth = importlib.import_module("fpv_amd.synth")
+
+
+def ref_stream_sha(frames, total, xs, ys, shift, threads=8):
+    p = subprocess.Popen([os.path.join(ROOT, "oracle", "_ref", "encode"), str(xs), str(ys), "0", str(shift), str(threads)],
+                         stdin=subprocess.PIPE, stdout=subprocess.PIPE)
+    h, size = hashlib.sha256(), 0
+
+    import threading
+    def feed():
+        for i in range(total):
+            p.stdin.write(frames[i % len(frames)].tobytes())
+        p.stdin.close()
+    t = threading.Thread(target=feed); t.start()
+    while True:
+        b = p.stdout.read(1 << 22)
+        if not b:
+            break
+        h.update(b); size += len(b)
+    t.join(); assert p.wait() == 0
+    return h.hexdigest(), size
+
+
+def main():
+    man = json.load(open(os.path.join(HERE, "manifest.json")))
+    fr = synth.plasma_frames(64, 1280, 800, bits=12, seed=7)
+    sha, size = ref_stream_sha(fr, 1000, 1280, 800, 4)
+    man["workloads"]["plasma12_1280x800x1000_cycled64_seed7"] = {
+        "xs": 1280, "ys": 800, "shift": 4, "big_endian": False, "frames": 1000, "distinct": 64,
+        "note": "frame i = synth.plasma_frames(64, 1280, 800, bits=12, seed=7)[i % 64]; delta frame = frame 0 (encode.cc:87-90)",
+        "fpv_sha256": sha, "fpv_size": size, "generator": "tests/golden/make_golden_long.py"}
+    json.dump(man, open(os.path.join(HERE, "manifest.json"), "w"), indent=1)
+    print(sha, size)
+
+
+if __name__ == "__main__":
+    main()

@@ -42,6 +42,8 @@ int fpvhip_device_count(void) {
 const char *fpvhip_last_error(const fpvhip_ctx *c) { return c ? c->err : g_err; }
 int fpvhip_warmup(int device) { (void)device; return 0; }
 int fpvhip_prepare_slot(fpvhip_ctx *c, uint32_t slot) { (void)c; (void)slot; return 0; }
+size_t fpvhip_staging_bytes(const fpvhip_ctx *c) { return c ? (size_t)c->nslots * c->batch * c->npix * 4 : 0; }
+int fpvhip_trim(fpvhip_ctx *c) { (void)c; return 0; }
 int fpvhip_debug_counters(fpvhip_ctx *c, uint32_t *out, uint32_t n) { (void)c; (void)out; (void)n; return -1; }
 double fpvhip_slot_elapsed_ms(fpvhip_ctx *c, uint32_t slot) { (void)c; (void)slot; return 0.0; }
 double fpvhip_time_copy_device(void *d, const void *s, size_t b, void *st, int it) { (void)d; (void)s; (void)b; (void)st; (void)it; return -1.0; }

@@ -74,5 +74,50 @@ int main() {
   b.join();
   if (r1 || r2) return 10 + r1 + r2;
   printf("concurrent sessions ok\n");
+  {
+    // Two threads call DecodeFrames on ONE decoder, each request spanning several GPU
+    // batches: with two slots per engine each caller used to end up holding one slot and
+    // waiting for the other's.  A third thread decodes single frames meanwhile.
+    const size_t xs = 64, ys = 48, n = 120;
+    std::vector<uint16_t> fr(n * xs * ys);
+    uint32_t s = 777;
+    for (auto& v : fr) { s = s * 1664525u + 1013904223u; v = (s >> 16) & 0xfff; }
+    setenv("FPV_DECODE_BATCH", "8", 1);
+    setenv("FPV_SHIM_DEVICES", "2", 1);
+    std::vector<uint8_t> out;
+    {
+      fpvc::Encoder enc(4, 4, false);
+      enc.Init(fr.data(), xs, ys, Append, &out);
+      for (size_t i = 0; i < n; i++) enc.CompressFrame(&fr[i * xs * ys], Append, &out);
+      enc.Finish(Append, &out);
+    }
+    fpvc::RandomAccessDecoder dec;
+    if (!dec.Init(out.data(), out.size())) return 20;
+    auto many = [&](size_t first, size_t count, int* rc) {
+      std::vector<size_t> idx(count);
+      std::vector<uint16_t> back(count * xs * ys);
+      std::vector<uint16_t*> outp(count);
+      for (size_t i = 0; i < count; i++) { idx[i] = (first + i) % n; outp[i] = &back[i * xs * ys]; }
+      for (int rep = 0; rep < 3; rep++) {
+        if (!dec.DecodeFrames(idx.data(), count, outp.data(), 3)) { *rc = 1; return; }
+        for (size_t i = 0; i < count; i++)
+          for (size_t k = 0; k < xs * ys; k++)
+            if (back[i * xs * ys + k] != (uint16_t)(fr[idx[i] * xs * ys + k] << 4)) { *rc = 2; return; }
+      }
+      *rc = 0;
+    };
+    int ra = -1, rb = -1, rc = 0;
+    std::thread ta([&] { many(0, 50, &ra); }), tb([&] { many(30, 70, &rb); });
+    std::thread tc([&] {
+      std::vector<uint16_t> one(xs * ys);
+      for (size_t i = 0; i < 40; i++) {
+        if (!dec.DecodeFrame((i * 7) % n, one.data())) { rc = 1; return; }
+        if (one[5] != (uint16_t)(fr[((i * 7) % n) * xs * ys + 5] << 4)) { rc = 2; return; }
+      }
+    });
+    ta.join(); tb.join(); tc.join();
+    if (ra || rb || rc) return 30 + ra + rb + rc;
+    printf("concurrent DecodeFrames on one decoder ok\n");
+  }
   return 0;
 }

@@ -67,3 +67,19 @@ def test_product_never_links_the_oracle():
     for so in ("libfpvhip.so", "libfpv_amd.so"):
         out = subprocess.run(["nm", "-D", os.path.join(LIB, so)], capture_output=True, text=True).stdout
         assert "fpvo_" not in out, f"{so} references the test oracle"
+
+
+def test_unsupported_geometry_is_a_clean_error():
+    """Geometries the forward kernels cannot take fail in fpvhip_create with a message (no
+    abort, no GPU needed to find out): odd sizes, frames wider than the LDS line buffers."""
+    import ctypes
+    lib = ctypes.CDLL(os.path.join(ROOT, "fusion-power-video_amd", "lib", "libfpvhip.so"))
+    lib.fpvhip_create.restype = ctypes.c_void_p
+    lib.fpvhip_create.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_int,
+                                  ctypes.c_uint32, ctypes.c_uint32]
+    lib.fpvhip_last_error.restype = ctypes.c_char_p
+    lib.fpvhip_last_error.argtypes = [ctypes.c_void_p]
+    for xs, ys, shift, what in ((65536, 4, 0, b"too large"), (1282, 800, 0, b"multiples of 4"),
+                                (1280, 798, 0, b"multiples of 4"), (1280, 800, 16, b"shift")):
+        assert not lib.fpvhip_create(0, xs, ys, shift, 0, 1, 1)
+        assert what in lib.fpvhip_last_error(None), (xs, ys, lib.fpvhip_last_error(None))

@@ -1,0 +1,99 @@
+"""Drop-in proof under pytest: the UPSTREAM encode.cc / decode.cc / benchmark.cc, compiled
+unchanged against include/fusion_power_video.h + libfpv_amd.so (build/bin/ref_*, built where
+/root/reference exists and shipped with the tree), run on the GPU; compared with the CPU
+reference binaries (oracle/_ref, the checker) on the same input and the same host."""
+import hashlib
+import json
+import os
+import re
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "build", "bin")
+REF = os.path.join(ROOT, "oracle", "_ref")
+
+
+def _have(*paths):
+    return all(os.path.exists(p) for p in paths)
+
+
+@pytest.fixture(scope="module")
+def raw100(synth):
+    with tempfile.TemporaryDirectory(dir="/tmp") as d:
+        p = os.path.join(d, "plasma100.raw")
+        synth.plasma_frames(100, 1280, 800, bits=12).tofile(p)
+        yield p
+
+
+def _run(cmd, stdin_path=None, timeout=120):
+    with open(stdin_path, "rb") if stdin_path else open(os.devnull, "rb") as f:
+        return subprocess.run(cmd, stdin=f, capture_output=True, timeout=timeout)
+
+
+@pytest.mark.skipif(not _have(os.path.join(BIN, "ref_encode"), os.path.join(BIN, "ref_decode")),
+                    reason="upstream CLIs over this library were not built (no /root/reference at build time)")
+def test_upstream_encode_decode_over_the_library(raw100):
+    args = ["1280", "800", "0", "4"]   # xsize ysize big_endian shift (enc:41-44)
+    shas = {}
+    for t in ("0", "8"):
+        r = _run([os.path.join(BIN, "ref_encode")] + args + [t], raw100)
+        assert r.returncode == 0, r.stderr[-500:]
+        shas["upstream encode.cc on the GPU library, threads " + t] = hashlib.sha256(r.stdout).hexdigest()
+        stream = r.stdout
+    r = _run([os.path.join(BIN, "fpv_encode")] + args + ["16"], raw100)
+    assert r.returncode == 0
+    shas["own fpv_encode"] = hashlib.sha256(r.stdout).hexdigest()
+    if _have(os.path.join(REF, "encode")):
+        r = _run([os.path.join(REF, "encode")] + args + ["8"], raw100)
+        assert r.returncode == 0
+        shas["CPU reference encode"] = hashlib.sha256(r.stdout).hexdigest()
+    assert len(set(shas.values())) == 1, shas
+    raw = open(raw100, "rb").read()
+    with tempfile.NamedTemporaryFile(dir="/tmp", suffix=".fpv") as f:
+        f.write(stream)
+        f.flush()
+        decoders = [[os.path.join(BIN, "ref_decode")] + args, [os.path.join(BIN, "fpv_decode"), "0", "4"]]
+        if _have(os.path.join(REF, "decode")):
+            decoders.append([os.path.join(REF, "decode")] + args)
+        for cmd in decoders:
+            r = _run(cmd, f.name)
+            assert r.returncode == 0 and r.stdout == raw, cmd
+
+
+def _bench_ms(binary, raw, threads, reps=3):
+    best = None
+    for _ in range(reps):
+        r = subprocess.run([binary, raw, "1280", "800", "0", "4", "100", str(threads)], capture_output=True, text=True, timeout=120)
+        m = re.search(r"^total: .*time: ([0-9.]+) ms", r.stderr, re.M)
+        assert r.returncode == 0 and m, r.stderr[-800:]
+        assert "roundtrip not equal" not in r.stderr and r.stderr.count("ok") >= 2   # both decoders verified
+        best = min(best or 1e9, float(m.group(1)))
+    return best
+
+
+@pytest.mark.skipif(not _have(os.path.join(BIN, "ref_benchmark"), os.path.join(REF, "benchmark")),
+                    reason="needs the upstream benchmark built over this library and the CPU reference build")
+def test_upstream_benchmark_cold_start_vs_cpu_reference(raw100):
+    """benchmark.cc:153-180 times Encoder construction -> Finish of a FRESH process: 100 frames
+    1280x800, this library under the unchanged upstream benchmark against the CPU reference
+    on the same box, best of three each.  Round 1 lost this at 32 and 64 threads (pinned
+    allocations and stream creation inside the timer)."""
+    table = {}
+    for t in (8, 32, 64):
+        ours = _bench_ms(os.path.join(BIN, "ref_benchmark"), raw100, t)
+        ref = _bench_ms(os.path.join(REF, "benchmark"), raw100, t)
+        table[t] = {"gpu_library_ms": ours, "cpu_reference_ms": ref, "fps_ratio": round(ref / ours, 3)}
+    print(json.dumps(table))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(table, open(os.path.join(ROOT, "gpurun_out", "upstream_benchmark_vs_reference.json"), "w"), indent=1)
+    # Timing on a shared box swings (both sides burst beyond the CPU quota for a job this
+    # short): the bounds catch a regression to round 1 (0.5-0.6 at 32 and 64 threads), the
+    # table itself goes to gpurun_out/ and DESIGN.md.
+    assert table[8]["fps_ratio"] >= 0.9, table
+    assert table[32]["fps_ratio"] >= 0.9, table
+    assert table[64]["fps_ratio"] >= 0.7, table

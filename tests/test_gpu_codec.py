@@ -60,7 +60,7 @@ def test_callback_order_and_payloads(codec, synth):
     assert ids == [1000000] + list(range(1, 41)) + [2000000]
 
 
-@pytest.mark.parametrize("xs,ys", [(30, 22), (5, 3), (1, 7), (257, 9), (1284, 6)])
+@pytest.mark.parametrize("xs,ys", [(30, 22), (5, 3), (1, 7), (257, 9), (1284, 6), (1, 1), (3, 1), (1, 2)])
 def test_decoders_accept_odd_sizes(codec, oracle, xs, ys):
     """Files written by the CPU reference may have any size (only ENCODING needs
     multiples of 4): the byte-granular inverse kernel decodes them."""
@@ -165,3 +165,21 @@ def test_concurrent_sessions_in_one_process(codec, synth):
         for i, (fr, xs, ys, shift) in enumerate(jobs):
             assert np.array_equal(results[i], alone[i]), f"session {i} differs when run concurrently"
             assert np.array_equal(decoded[i], fr << shift)
+
+
+def test_two_contexts_on_one_device(codec, oracle, synth, monkeypatch):
+    """FPV_DEVICES=0,0: the in-process multi-GPU paths on real HIP -- two forward contexts (own
+    slots, own stream sets) feeding one Encoder round-robin, and DecodeFrames sharded over two
+    inverse engines.  Bytes and pixels identical to the single-context run (cc:1179-1183: the
+    only serial point is the in-order callback + index)."""
+    fr = synth.plasma_frames(70, 320, 200, bits=12, seed=11)
+    one = codec.encode_stream(fr, fr[0], 320, 200, 4, False, threads=6)
+    assert np.array_equal(one, oracle.encode_stream(fr, fr[0], 320, 200, 4, False))
+    monkeypatch.setenv("FPV_DEVICES", "0,0")
+    monkeypatch.setenv("FPV_BATCH", "4")
+    monkeypatch.setenv("FPV_DECODE_BATCH", "8")
+    two = codec.encode_stream(fr, fr[0], 320, 200, 4, False, threads=6)
+    assert np.array_equal(one, two)
+    dec = codec.decode_stream(two, batched=True, threads=6)      # 70 frames / batch 8: two shards
+    assert np.array_equal(dec, fr << 4)
+    assert np.array_equal(codec.decode_stream_raw(two, shift=4, threads=6).view(np.uint16).reshape(70, 200, 320), fr)

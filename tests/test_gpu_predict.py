@@ -56,7 +56,7 @@ def test_no_delta_frame(fpv, synth, oracle):
     _run_case(fpv, oracle, fr, 1280, 800, 4, False, None)
 
 
-@pytest.mark.parametrize("xs,ys", [(64, 48), (4, 4), (8, 4), (4096, 8), (1920, 1080), (36, 20), (6144, 8), (8192, 4)])
+@pytest.mark.parametrize("xs,ys", [(64, 48), (4, 4), (8, 4), (4096, 8), (1920, 1080), (36, 20), (6144, 8), (8192, 4), (8196, 4), (16384, 8), (32768, 4)])
 def test_shapes(fpv, synth, oracle, xs, ys):
     fr = synth.noise_frames(3, xs, ys, seed=3)
     fr[1] = (fr[1] >> 9) + 3000          # smooth-ish: exercises the CG-on branch

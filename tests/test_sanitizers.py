@@ -17,4 +17,5 @@ def test_threadsanitizer_host_pipeline():
         pytest.skip("no libtsan in this toolchain")
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert r.stdout.count(" ok, ") == 4 and "concurrent sessions ok" in r.stdout
+    assert "concurrent DecodeFrames on one decoder ok" in r.stdout   # used to deadlock (two slots per engine)
     assert r.stdout.count("columnar ok") == 5   # the columnar adapter's queues and futures

@@ -98,7 +98,16 @@ endif
 # the CPU test shim, and (where the upstream tree is present) the upstream columnar
 # tests compiled UNCHANGED against OUR columnar headers (symlinked so that their quoted
 # includes resolve to include/columnar_batch/).
-columnar: $(BINDIR)/columnar_driver tests/shim/columnar_driver_cpushim
+columnar: $(BINDIR)/columnar_driver tests/shim/columnar_driver_cpushim $(BINDIR)/columnar_dump tests/shim/columnar_dump_cpushim
+# format-parity dump of the native Batch (tests/columnar_dump.cc; the reference build of the same
+# source lives in oracle/_ref)
+$(BINDIR)/columnar_dump: tests/columnar_dump.cc $(LIBDIR)/libfpv_amd.so $(wildcard include/columnar_batch/*.h)
+	@mkdir -p $(BINDIR)
+	$(CXX) -std=c++14 -O2 -Wall -Iinclude/columnar_batch $< -L$(LIBDIR) -lfpv_amd -lfpvhip -lpthread \
+	    -Wl,-rpath,'$$ORIGIN/../../$(LIBDIR)' -Wl,-rpath,$(ROCM_LIB) -o $@
+tests/shim/columnar_dump_cpushim: tests/columnar_dump.cc tests/shim/libfpv_amd_cpushim.so $(wildcard include/columnar_batch/*.h)
+	$(CXX) -std=c++14 -O2 -Wall -Iinclude/columnar_batch $< tests/shim/libfpv_amd_cpushim.so -lpthread \
+	    -Wl,-rpath,'$$ORIGIN' -o $@
 $(BINDIR)/columnar_driver: tests/columnar_driver.cc $(LIBDIR)/libfpv_amd.so $(wildcard include/columnar_batch/*.h)
 	@mkdir -p $(BINDIR)
 	$(CXX) -std=c++14 -O2 -Wall -Iinclude/columnar_batch $< -L$(LIBDIR) -lfpv_amd -lfpvhip -lpthread \
@@ -123,7 +132,16 @@ PYARROW := $(shell python3 -c "import pyarrow, sys; sys.stdout.write(pyarrow.get
 ARROW_SO := $(firstword $(wildcard $(PYARROW)/libarrow.so.[0-9]*))
 ifneq ($(ARROW_SO),)
 ARROWFLAGS := -std=c++20 -O2 -fPIC -Wall -Iinclude -I$(CSRC) -I$(PYARROW)/include
-arrow: $(LIBDIR)/libfpv_arrow.so $(BINDIR)/arrow_driver tests/shim/arrow_driver_cpushim
+arrow: $(LIBDIR)/libfpv_arrow.so $(BINDIR)/arrow_driver tests/shim/arrow_driver_cpushim $(BINDIR)/arrow_dump tests/shim/arrow_dump_cpushim
+# format-parity dump of the native Arrow adapter (tests/arrow_dump.cc; the reference build of the
+# same source lives in oracle/_ref)
+$(BINDIR)/arrow_dump: tests/arrow_dump.cc $(LIBDIR)/libfpv_arrow.so
+	@mkdir -p $(BINDIR)
+	$(CXX) $(ARROWFLAGS) -Iinclude/fpv_arrow $< -L$(LIBDIR) -lfpv_arrow -lfpv_amd -lfpvhip $(ARROW_SO) -lpthread \
+	    -Wl,-rpath,'$$ORIGIN/../../$(LIBDIR)' -Wl,-rpath,$(ROCM_LIB) -Wl,-rpath,$(PYARROW) -o $@
+tests/shim/arrow_dump_cpushim: tests/arrow_dump.cc $(CSRC)/fpv_arrow.cc tests/shim/libfpv_amd_cpushim.so
+	$(CXX) $(ARROWFLAGS) -Iinclude/fpv_arrow tests/arrow_dump.cc $(CSRC)/fpv_arrow.cc tests/shim/libfpv_amd_cpushim.so $(ARROW_SO) -lpthread \
+	    -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,$(PYARROW) -o $@
 $(LIBDIR)/libfpv_arrow.so: $(CSRC)/fpv_arrow.cc $(wildcard include/fpv_arrow/*.h) $(LIBDIR)/libfpv_amd.so
 	$(CXX) $(ARROWFLAGS) -shared $< -L$(LIBDIR) -lfpv_amd $(ARROW_SO) -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,$(PYARROW) -o $@
 $(BINDIR)/arrow_driver: tests/arrow_driver.cc $(LIBDIR)/libfpv_arrow.so
@@ -197,7 +215,7 @@ build/tsan/driver: tests/shim/tsan_driver.cc tests/shim/fpvhip_oracle_shim.c ora
 	$(CXX) $(CXXFLAGS) -O1 -g -fsanitize=thread tests/shim/tsan_driver.cc $(HOST_SRC) build/tsan/shim.o build/tsan/oracle.o $(BROTLI) -o $@
 
 clean:
-	rm -rf $(LIBDIR) build tests/shim/*.so tests/shim/*.o tests/shim/columnar_driver_cpushim tests/shim/arrow_driver_cpushim
+	rm -rf $(LIBDIR) build tests/shim/*.so tests/shim/*.o tests/shim/*_cpushim
 	$(MAKE) -C oracle clean
 
 .PHONY: all product tools oracle shim refcli refcb columnar arrow asan tsan clean

@@ -84,3 +84,43 @@ def test_upstream_arrow_adapter_over_frame_api():
         pytest.xfail(f"upstream adapter crashed on its own race (signal {-r.returncode})")
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "Closed - 234567." in r.stdout
+
+
+# ---- format parity with the reference's RecordBatch (arrow/arrow_encoder.cc:78-141) ----------
+#
+# tests/golden/arrow_reference.arrows is the Arrow IPC stream of the record batches the UPSTREAM
+# ArrowEncoder emitted for the frames stored in tests/golden/columnar.npz (4 frames, 3 per batch;
+# tests/golden/make_golden_columnar.py, upstream arrow_encoder.cc over the upstream library,
+# driven by tests/arrow_dump.cc).  The native adapter must produce the same bytes: schema, field
+# order, metadata keys and values (the delta frame's Brotli streams), every column buffer.
+
+def _arrow_parity(dump_binary):
+    import tempfile
+
+    import numpy as np
+    if not os.path.exists(dump_binary):
+        pytest.skip(f"{os.path.relpath(dump_binary, ROOT)} not built (make arrow; needs pyarrow's Arrow C++)")
+    g = np.load(os.path.join(ROOT, "tests", "golden", "columnar.npz"))
+    want = open(os.path.join(ROOT, "tests", "golden", "arrow_reference.arrows"), "rb").read()
+    with tempfile.TemporaryDirectory() as d:
+        raw = os.path.join(d, "frames.raw")
+        g["frames"].tofile(raw)
+        r = subprocess.run([dump_binary, raw, "320", "200", "4", "4", "3"], capture_output=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-500:]
+    if r.stdout != want:   # say where, then fail
+        pa = pytest.importorskip("pyarrow")
+        a, b = pa.ipc.open_stream(want), pa.ipc.open_stream(r.stdout)
+        assert a.schema.equals(b.schema, check_metadata=True), (a.schema, b.schema)
+        for x, y in zip(a, b):
+            for i, name in enumerate(x.schema.names):
+                assert x.column(i).equals(y.column(i)), name
+    assert r.stdout == want
+
+
+def test_arrow_stream_identical_to_reference_over_cpu_shim():
+    _arrow_parity(os.path.join(ROOT, "tests", "shim", "arrow_dump_cpushim"))
+
+
+@pytest.mark.gpu
+def test_arrow_stream_identical_to_reference_on_gpu():
+    _arrow_parity(os.path.join(BIN, "arrow_dump"))

@@ -7,7 +7,7 @@ TAG=${1:-r01}
 export TMPDIR=/tmp
 run() {  # name counters...
   local name=$1; shift
-  timeout 300 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmc_$TAG/$name -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_$TAG/$name.log 2>&1
+  timeout 300 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmc_$TAG/$name -- python3 bench.py --steps 2 --warmup 1 --quick > gpurun_out/pmc_$TAG/$name.log 2>&1
 }
 mkdir -p gpurun_out/pmc_$TAG
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU

@@ -3,19 +3,19 @@
 # PMC passes (separate runs, no tracing domains mixed in).  Output: gpurun_out/<tag>/
 set -u
 cd "$(dirname "$0")/.."
-TAG=${1:-r01}
+TAG=${1:-r02}
 export TMPDIR=/tmp
 mkdir -p gpurun_out/$TAG
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$TAG/trace -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/$TAG/bench_under_rocprof.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$TAG/trace -- python3 bench.py --steps 200 --warmup 5 --quick > gpurun_out/$TAG/bench_under_rocprof.log 2>&1
 cp $(find gpurun_out/$TAG/trace -name "*kernel_stats.csv" | head -1) gpurun_out/$TAG/kernel_stats.csv
 echo "[$(date +%T)] trace done"
 bash tools/prof_pmc.sh $TAG > /dev/null 2>&1
 echo "[$(date +%T)] pmc done"
-python3 tools/pmc_summary.py gpurun_out/pmc_$TAG k_stream > gpurun_out/$TAG/pmc_k_stream.json
+python3 tools/pmc_summary.py gpurun_out/pmc_$TAG k_stream\< > gpurun_out/$TAG/pmc_k_stream.json
 python3 tools/pmc_summary.py gpurun_out/pmc_$TAG k_inverse_spec > gpurun_out/$TAG/pmc_k_inverse_spec.json
 python3 tools/traffic_from_pmc.py gpurun_out/pmc_$TAG > gpurun_out/$TAG/traffic.json
 cp gpurun_out/$TAG/traffic.json profiles/traffic.json   # bench.py reads it (same box, same build)
-timeout -k 10 300 python3 bench.py > gpurun_out/$TAG/bench.log 2>&1
+timeout -k 10 500 python3 bench.py > gpurun_out/$TAG/bench.log 2>&1
 grep "^{" gpurun_out/$TAG/bench.log > gpurun_out/$TAG/bench.json
 rm -rf gpurun_out/$TAG/trace gpurun_out/pmc_$TAG/*/*/*.db 2>/dev/null
 cat gpurun_out/$TAG/kernel_stats.csv | cut -c1-160 | head -8

@@ -67,6 +67,9 @@ def _declare_hip(lib):
     lib.fpvhip_time_copy_device.argtypes = [vp, vp, c.c_size_t, vp, i32]
     lib.fpvhip_time_inverse_device.restype = c.c_double
     lib.fpvhip_time_inverse_device.argtypes = [vp, vp, vp, vp, u32, vp, vp, i32]
+    if hasattr(lib, "fpvhip_inverse_kernel_name"):   # absent from older diagnostic builds (tools/ab_*.py)
+        lib.fpvhip_inverse_kernel_name.restype = c.c_char_p
+        lib.fpvhip_inverse_kernel_name.argtypes = [vp, u32]
     lib.fpvhip_debug_counters.restype = i32
     lib.fpvhip_debug_counters.argtypes = [vp, c.POINTER(c.c_uint32), u32]
     lib.fpvhip_inverse_pass_stats.restype = i32
@@ -225,8 +228,7 @@ class Predictor:
 
     def inverse_kernel_name(self, nframes):
         """Which inverse kernel launch_inverse picks for this batch size (FPV_INVERSE unset)."""
-        cus = torch.cuda.get_device_properties(self.device).multi_processor_count
-        return "k_inverse_trio" if nframes <= 3 * cus else "k_inverse_spec"
+        return self.lib.fpvhip_inverse_kernel_name(self.ctx, nframes).decode()
 
     def inverse_pass_stats(self, reset=True):
         """(supersteps, passes) of the speculative inverse kernel since the last reset;

@@ -714,6 +714,12 @@ double fpvhip_slot_elapsed_ms(fpvhip_ctx* c, uint32_t slot) {
   return ms;
 }
 
+const char* fpvhip_inverse_kernel_name(fpvhip_ctx* c, uint32_t nframes) {
+  if (!c) return "";
+  hipSetDevice(c->device);
+  return fpvhip::inverse_kernel_name(c->g, nframes);
+}
+
 int fpvhip_inverse_pass_stats(fpvhip_ctx* c, uint32_t* out, int reset) {
   if (!c || !out) return fail(c, "bad arguments");
   HIPOK(c, hipSetDevice(c->device));

@@ -101,5 +101,8 @@ hipError_t launch_inverse(const Geom& g, const uint8_t* d_high,
                           uint32_t nframes, uint16_t* d_frames, hipStream_t s,
                           uint32_t* d_diag = nullptr);
 
+// Name of the kernel launch_inverse picks for a batch of nframes (diagnostics, bench).
+const char* inverse_kernel_name(const Geom& g, uint32_t nframes);
+
 }  // namespace fpvhip
 #endif  // FPV_KERNELS_H_

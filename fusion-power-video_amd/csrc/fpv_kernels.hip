@@ -448,8 +448,9 @@ __device__ __forceinline__ void stream_load(const StreamCtx& c, uint32_t it, uin
     p->a = ld_stream(src);
     p->b = ld_stream(src + 8);
     if (DELTA) {
-      p->dh = *reinterpret_cast<const uint4*>(c.dh + c.s + o);
-      if (LOW) p->dl = *reinterpret_cast<const uint4*>(c.dl + c.s + o);
+      const uint32_t od = (FPV_ABL & 256) ? c.lane * 16 : c.s + o;  // 256: always the same 1 KiB (L1 hits): what do the delta MISSES cost?
+      p->dh = *reinterpret_cast<const uint4*>(c.dh + od);
+      if (LOW) p->dl = *reinterpret_cast<const uint4*>(c.dl + od);
     }
   } else {
     const uint32_t o = it * kStep + c.lane * 16;
@@ -1581,23 +1582,28 @@ __global__ __launch_bounds__(64) void k_inverse_spec(
     }
   };
   fetch_r(head, rq);
+  // Operands of the output phase (low plane, delta planes: coalesced, 4 pixels per lane and
+  // round) are fetched ONE SUPERSTEP AHEAD, and issued in FRONT of the previous superstep's
+  // stores: a vector-memory wait is in issue order, so a load queued behind stores would
+  // make its consumer wait for the stores' acknowledgements too (with the loads issued at
+  // the top of their own superstep a third of the wave's cycles went into such waits).
+  uint32_t l4n[K4], dh4n[K4], dl4n[K4];
+  auto fetch_out = [&](uint32_t s0) {
+#pragma unroll
+    for (int t = 0; t < K4; t++) {
+      const uint32_t ic = min(s0 + (t * 64 + lane) * 4, last4);
+      l4n[t] = *reinterpret_cast<const uint32_t*>(lsrc + ic);   // raw: masked where they are consumed, so that
+      dh4n[t] = *reinterpret_cast<const uint32_t*>(dhsrc + ic);  // nothing touches a loaded value (= waits for
+      dl4n[t] = *reinterpret_cast<const uint32_t*>(dlsrc + ic);  // it) before the output phase
+    }
+  };
+  fetch_out(head);
   uint32_t npass = 0, maxpass = 0;
 
   auto superstep = [&](uint32_t s0, auto full_tag) {
     constexpr bool FULL = decltype(full_tag)::value;
     const uint32_t start = s0 + lane * K;
     const bool active = FULL || start < npix;
-    // operands of the output phase (coalesced, 4 pixels per lane and round): in
-    // flight while the chain passes run
-    uint32_t l4[K4], dh4[K4], dl4[K4];
-#pragma unroll
-    for (int t = 0; t < K4; t++) {
-      const uint32_t i = s0 + (t * 64 + lane) * 4;
-      const uint32_t ic = FULL ? i : min(i, last4);
-      l4[t] = *reinterpret_cast<const uint32_t*>(lsrc + ic) & lmask;
-      dh4[t] = *reinterpret_cast<const uint32_t*>(dhsrc + ic) & dmask;
-      dl4[t] = *reinterpret_cast<const uint32_t*>(dlsrc + ic) & dmask;
-    }
     // segment operands into registers, everything as v << 8
     uint32_t N[K], D[K], R[K], X[K];
     uint32_t guess;
@@ -1707,14 +1713,18 @@ __global__ __launch_bounds__(64) void k_inverse_spec(
 #pragma unroll
     for (int t = 0; t < K4; t++)
       h4[t] = *reinterpret_cast<const uint32_t*>(ring + ((s0 + (t * 64 + lane) * 4) & m));
+    uint2 px[K4];
 #pragma unroll
     for (int t = 0; t < K4; t++) {  // delta^-1 + recombine (cc:335-344); absent planes are zeros
+      const uint32_t hh = add4(h4[t], dh4n[t] & dmask), ll = add4(l4n[t] & lmask, dl4n[t] & dmask);
+      px[t].x = __builtin_amdgcn_perm(hh, ll, 0x05010400u);
+      px[t].y = __builtin_amdgcn_perm(hh, ll, 0x07030602u);
+    }
+    fetch_out(s0 + S);  // the next superstep's operands (the registers are free now), in front of this one's stores
+#pragma unroll
+    for (int t = 0; t < K4; t++) {
       const uint32_t i = s0 + (t * 64 + lane) * 4;
-      const uint32_t hh = add4(h4[t], dh4[t]), ll = add4(l4[t], dl4[t]);
-      uint2 o;
-      o.x = __builtin_amdgcn_perm(hh, ll, 0x05010400u);
-      o.y = __builtin_amdgcn_perm(hh, ll, 0x07030602u);
-      if (FULL || i < npix) *reinterpret_cast<uint2*>(outp + i) = o;
+      if (FULL || i < npix) *reinterpret_cast<uint2*>(outp + i) = px[t];
     }
     wave_lds_sync();
   };
@@ -2372,6 +2382,55 @@ hipError_t launch_predict(const Geom& g, const uint16_t* d_frames,
                              d_low, d_preview, d_flags, s, ev);
 }
 
+// Frames whose three-wave workgroups (k_inverse_trio) are all resident at the same time on
+// the current device: workgroups per CU as the runtime's occupancy query sees them (register
+// and LDS budget of the instantiation for this geometry) times the CUs.  Cached per device / K4.
+static uint32_t trio_capacity(const Geom& g) {
+  static std::mutex m;
+  static uint32_t cap[64][kSpecMaxK4 + 1] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  dev &= 63;
+  const uint32_t k4 = g.spec_k4;
+  if (k4 == 0 || k4 > kSpecMaxK4) return 0;
+  std::lock_guard<std::mutex> l(m);
+  if (!cap[dev][k4]) {
+    int blocks = 0;
+    const size_t lds = g.spec_ring + 10 * 256 * k4;
+    hipError_t e = hipErrorInvalidValue;
+    switch (k4) {
+#define FPV_OCC(K4) case K4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_inverse_trio<K4>, 192, lds); break;
+      FPV_OCC(1) FPV_OCC(2) FPV_OCC(3) FPV_OCC(4) FPV_OCC(5) FPV_OCC(6)
+#undef FPV_OCC
+    }
+    if (e != hipSuccess || blocks <= 0) blocks = 3;
+    cap[dev][k4] = (uint32_t)blocks * device_cus();
+  }
+  return cap[dev][k4];
+}
+
+// Which inverse kernel a batch of nframes takes: 3 three waves per frame, 0 one wave per
+// frame (speculative), 1 the serial-chain kernel, 2 the byte-granular one.
+static int inverse_mode(const Geom& g, uint32_t nframes) {
+  int mode = -1;  // the environment is read per launch: tests switch kernels inside one process
+  if (getenv("FPV_INVERSE_SLOW")) {
+    mode = 2;
+  } else if (const char* e = getenv("FPV_INVERSE")) {
+    mode = e[0] == 'f' ? 1 : e[0] == 's' && e[1] == 'l' ? 2 : e[0] == 's' ? 0 : e[0] == 't' ? 3 : -1;
+  }
+  if (mode < 0) mode = g.spec_k4 && nframes <= trio_capacity(g) ? 3 : 0;
+  return mode;
+}
+
+const char* inverse_kernel_name(const Geom& g, uint32_t nframes) {
+  const int mode = inverse_mode(g, nframes);
+  const bool aligned = (g.xs & 3) == 0 && (g.npix & 3) == 0;
+  if (mode == 3 && g.spec_k4) return "k_inverse_trio";
+  if (mode == 0 && g.spec_k4) return "k_inverse_spec";
+  if (mode != 2 && aligned && g.xs >= kInvC && (g.inv_ring + 4 * kInvC) * 4 <= 160 * 1024 - 64) return "k_inverse_fast";
+  return "k_inverse";
+}
+
 hipError_t launch_inverse(const Geom& g, const uint8_t* d_high,
                           const uint8_t* d_low, const uint8_t* d_dhigh,
                           const uint8_t* d_dlow, const uint8_t* d_flags,
@@ -2379,20 +2438,13 @@ hipError_t launch_inverse(const Geom& g, const uint8_t* d_high,
                           uint32_t* d_diag) {
   prepare_kernels();
   // FPV_INVERSE = auto (default) | trio | spec | fast | slow selects the kernel (tests, A/B timing).
-  // auto: three waves per frame (shorter serial path per frame) while every frame's
-  // chain wave can have a SIMD to itself most of the time, one wave per frame (less
-  // synchronisation, more frames resident) for larger batches.  Measured crossover
-  // on MI355X (256 CUs): between 768 and 1000 frames.
-  int mode = -1;  // read per launch: tests switch kernels inside one process
-  if (getenv("FPV_INVERSE_SLOW")) {
-    mode = 2;
-  } else if (const char* e = getenv("FPV_INVERSE")) {
-    mode = e[0] == 'f' ? 1 : e[0] == 's' && e[1] == 'l' ? 2 : e[0] == 's' ? 0 : e[0] == 't' ? 3 : -1;
-  }
-  if (mode < 0) {
-    const uint32_t ncu = device_cus();
-    mode = nframes <= 3u * ncu ? 3 : 0;
-  }
+  // auto: three waves per frame (shorter serial path per frame: 0.62 ms for a lone 1280x800
+  // frame, 0.90 ms for 1000 of them) as long as every frame's workgroup is resident at once,
+  // i.e. up to trio_capacity() frames (1024 at 1280x800 on MI355X: the register budget admits
+  // four such workgroups per CU); beyond that a second round of workgroups would run nearly
+  // alone, and one wave per frame (more frames resident, less synchronisation) wins:
+  // 1100 frames 1.35 ms against 1.56, 2000 frames 1.65 against 2.28 (profiles/r02_inverse_ab.log).
+  const int mode = inverse_mode(g, nframes);
   const bool aligned = (g.xs & 3) == 0 && (g.npix & 3) == 0;
   if (mode == 3 && g.spec_k4) {
 #define FPV_LAUNCH_TRIO(K4)                                                                     \

@@ -222,6 +222,9 @@ double fpvhip_slot_elapsed_ms(fpvhip_ctx *ctx, uint32_t slot);
  * spent on one frame, out[3] = most passes spent on one superstep.
  * Synchronises the device. */
 int fpvhip_inverse_pass_stats(fpvhip_ctx *ctx, uint32_t *out, int reset);
+/* Diagnostics: the inverse kernel a batch of nframes takes on this context's device
+ * ("k_inverse_trio", "k_inverse_spec", "k_inverse_fast", "k_inverse"). */
+const char *fpvhip_inverse_kernel_name(fpvhip_ctx *ctx, uint32_t nframes);
 /* Bench only: `iters` plain 16-B-per-lane device copies of `bytes` bytes on
  * `stream`; returns elapsed ms.  The measured HBM ceiling kernels are compared with. */
 double fpvhip_time_copy_device(void *d_dst, const void *d_src, size_t bytes,

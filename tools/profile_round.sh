@@ -12,7 +12,7 @@ echo "[$(date +%T)] trace done"
 bash tools/prof_pmc.sh $TAG > /dev/null 2>&1
 echo "[$(date +%T)] pmc done"
 python3 tools/pmc_summary.py gpurun_out/pmc_$TAG k_stream\< > gpurun_out/$TAG/pmc_k_stream.json
-python3 tools/pmc_summary.py gpurun_out/pmc_$TAG k_inverse_spec > gpurun_out/$TAG/pmc_k_inverse_spec.json
+python3 tools/pmc_summary.py gpurun_out/pmc_$TAG k_inverse_ > gpurun_out/$TAG/pmc_k_inverse.json
 python3 tools/traffic_from_pmc.py gpurun_out/pmc_$TAG > gpurun_out/$TAG/traffic.json
 cp gpurun_out/$TAG/traffic.json profiles/traffic.json   # bench.py reads it (same box, same build)
 timeout -k 10 500 python3 bench.py > gpurun_out/$TAG/bench.log 2>&1

@@ -23,7 +23,7 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
         if r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
             name = r["Kernel_Name"]
             key = ("k_stream" if "k_stream" in name else "k_redo_stream" if "k_redo_stream" in name else
-                   "k_inverse_spec" if "k_inverse_spec" in name else None)
+                   "k_inverse_spec" if "k_inverse_spec" in name else "k_inverse_trio" if "k_inverse_trio" in name else None)
             if key:
                 per[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {}

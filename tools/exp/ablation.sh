@@ -2,7 +2,7 @@
 set -u
 cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/abl
-for v in 0 1 2 4 8 16 32 64 6 14 30 127 0; do
+for v in 0 1 2 4 8 16 32 64 6 14 30 127 256 0; do
   FPV_HIP_LIB=$PWD/build/ab/libfpvhip_abl$v.so timeout -k 10 120 python tools/ab_forward.py plasma 30 2>&1 | grep "^{" | python3 -c "
 import sys,json
 for l in sys.stdin:

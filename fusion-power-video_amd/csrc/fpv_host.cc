@@ -362,6 +362,9 @@ struct Encoder::Impl {
   Batch* cur = nullptr;                       // batch being filled by the producer
   std::chrono::steady_clock::time_point cur_touched;
   std::deque<Batch*> gpu_q;                   // submitted, waiting for the GPU
+  std::vector<std::deque<Batch*>> ready_q;    // [dev] complete batches waiting for room on the device
+  std::vector<int> gpu_inflight;              // [dev] batches submitted and not yet back
+  int gpu_inflight_max = 3;
   std::deque<Task> work_q;                    // Brotli tasks
   std::deque<Task> copy_q;                    // staging copies (served first)
   struct Prep { int dev; uint32_t slot; };
@@ -414,7 +417,24 @@ struct Encoder::Impl {
   // enqueues copies and launches: the Brotli workers must not queue behind it); the
   // batch is closed and fully staged, so nothing else touches it meanwhile, and only
   // one thread ever gets `true` from CloseLocked / the last staging copy for it.
+  // At most kGpuInflight batches per device are queued on the GPU at a time; further complete
+  // batches wait in ready_q and are submitted by the dispatcher as earlier ones come back.
+  // Three keep copy-in, kernels and copy-out of consecutive batches overlapped; with more
+  // queued the runtime no longer keeps the two transfer directions on separate copy engines
+  // and the host link drops from 40 to 16-25 GB/s each way (tools/pcie_rate.py, 4-8 slots).
   void Submit(Batch* b) {
+    {
+      std::lock_guard<std::mutex> l(m);
+      if (gpu_inflight[b->dev] >= gpu_inflight_max) {
+        ready_q[b->dev].push_back(b);
+        return;
+      }
+      gpu_inflight[b->dev]++;
+    }
+    DoSubmit(b);
+  }
+
+  void DoSubmit(Batch* b) {
     CheckHip(fpvhip_predict_submit(ctxs[b->dev], b->slot, b->n, 1), ctxs[b->dev],
              "fpvhip_predict_submit");
     st_bytes_up += (uint64_t)b->n * npix * 2;
@@ -514,6 +534,15 @@ struct Encoder::Impl {
       b->done.assign(b->n, 0);
       for (uint32_t k = 0; k < b->n; k++) work_q.push_back(Task{b, k, nullptr});
       cv_work.notify_all();
+      gpu_inflight[b->dev]--;
+      if (!ready_q[b->dev].empty()) {  // the device has room again: hand it the next complete batch
+        Batch* nb = ready_q[b->dev].front();
+        ready_q[b->dev].pop_front();
+        gpu_inflight[nb->dev]++;
+        l.unlock();
+        DoSubmit(nb);
+        l.lock();
+      }
     }
   }
 
@@ -671,6 +700,9 @@ void Encoder::Init(const uint16_t* delta_frame, size_t xsize, size_t ysize,
   }
   s.slot_busy.assign(s.devices.size(), std::vector<char>(s.slots_per_dev, 0));
   s.slot_prepared.assign(s.devices.size(), std::vector<char>(s.slots_per_dev, 0));
+  s.ready_q.assign(s.devices.size(), std::deque<Impl::Batch*>());
+  s.gpu_inflight.assign(s.devices.size(), 0);
+  s.gpu_inflight_max = (int)std::max<size_t>(1, EnvSize("FPV_GPU_INFLIGHT", 3));
   for (auto& v : s.slot_prepared) v[0] = 1;  // slot 0 comes with the context
   const double t_ctx = now();
 

@@ -10,7 +10,9 @@ pkg = load_package(); synth = importlib.import_module('fpv_amd.synth')
 lib = pkg.hip_lib()
 XS, YS, SHIFT = 1280, 800, 4
 base = synth.plasma_frames(8, XS, YS, bits=12)
-for batch, slots in ((16, 3), (16, 6), (64, 3), (128, 2)):
+import os
+cases = [tuple(int(v) for v in c.split("x")) for c in os.environ.get("PCIE_CASES", "16x3,16x6,64x3,128x2").split(",")]
+for batch, slots in cases:
     ctx = lib.fpvhip_create(0, XS, YS, SHIFT, 0, batch, slots)
     assert ctx, pkg._err()
     assert lib.fpvhip_set_delta_raw(ctx, base[0].ctypes.data) == 0

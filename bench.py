@@ -318,6 +318,9 @@ def main():
                 res["e2e"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline and not args.quick:
             res["cpu_baseline"] = cpu_baseline(base, threads)
+            ref_fps = res["cpu_baseline"].get("encoder_fps", {}).get(str(threads))
+            if ref_fps and isinstance(res.get("e2e"), dict) and "fps" in res["e2e"]:
+                res["e2e"]["over_reference_encoder_same_threads"] = round(res["e2e"]["fps"] / ref_fps, 3)
         print(json.dumps(res), flush=True)
     pred.close()
     if dist is not None:

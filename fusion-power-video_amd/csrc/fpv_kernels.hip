@@ -79,7 +79,9 @@ __device__ __forceinline__ void split4(uint32_t va, uint32_t vb, int S,
 // asm on gfx950: measured wrong results.  Plain SWAR it stays.)
 __device__ __forceinline__ uint32_t sub4(uint32_t a, uint32_t b) {
   const uint32_t H = 0x80808080u;
-  return ((a | H) - (b & ~H)) ^ ((a ^ ~b) & H);
+  // ((a | H) - (b & ~H)) ^ ((a ^ ~b) & H); the last two operations as ONE three-input
+  // bit operation (v_bitop3_b32, truth table of t ^ (~x & H) over (x, H, t)): 5 VALU ops
+  return (uint32_t)__builtin_amdgcn_bitop3_b32((int)(a ^ b), (int)H, (int)((a | H) - (b & ~H)), 0xa6);
 }
 // Per-byte a + b (mod 256).
 __device__ __forceinline__ uint32_t add4(uint32_t a, uint32_t b) {
@@ -597,7 +599,9 @@ __device__ __forceinline__ void stream_step(StreamCtx& c, uint32_t it, const Pre
         // transposed: plane j holds quad j of every 16-pixel segment, so the 64 lanes of
         // one add hit 64 consecutive dwords (no bank conflicts)
         const uint32_t q4 = c.pw >> 2;
-        uint32_t* a = c.acc + ((c.row >> 2) & (c.nacc - 1)) * c.pw + (c.col >> 4);
+        const uint32_t slot = (c.row >> 2) & (c.nacc - 1);  // nacc is 2 or 4: two conditional adds, no multiply
+        const uint32_t slot_off = (uint32_t)(-(int)(slot & 1u)) & c.pw;
+        uint32_t* a = c.acc + slot_off + ((uint32_t)(-(int)(slot >> 1)) & (2u * c.pw)) + (c.col >> 4);
 #pragma unroll
         for (int j = 0; j < 4; j++) atomicAdd(a + j * q4, q[j]);
       } else {
@@ -634,7 +638,8 @@ __device__ __forceinline__ void stream_step(StreamCtx& c, uint32_t it, const Pre
     __builtin_amdgcn_wave_barrier();  // the reads below see the whole wave's ring writes
     FPV_STAMP(3);  // delta + low store + ring write
     if ((FPV_ABL & 2) && c.use_cg && !(FPV_ABL & 64)) st_stream(c.high_f + c.s + o, h);
-    uint4 r = h;
+    uint4 r;  // the clamped-gradient residuals of this segment (set when CG is applied)
+    if (FPV_ABL & 2) r = h;
     if (c.use_cg && !(FPV_ABL & 2)) {  // cc:566-571
       uint32_t n0, c0;
       uint4 nv;

@@ -134,6 +134,8 @@ def main():
     ap.add_argument("--frames", type=int, default=NFRAMES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--placement-trials", type=int, default=6,
+                    help="candidate buffer sets to allocate and time before the run; the fastest is used (1 = take the first)")
     ap.add_argument("--quick", action="store_true",
                     help="profiling runs (rocprofv3): only the headline workload and the inverse, few launches")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (RCCL, one GPU per rank) or gloo (rehearsal)")
@@ -168,9 +170,23 @@ def main():
     pred.set_delta_raw(base[0])
     d_base = torch.from_numpy(base.reshape(DISTINCT, -1).view(np.int16)).to(dev)
     idx = torch.arange(n, device=dev) % DISTINCT
-    d_frames = d_base[idx].contiguous().view(torch.uint16)
-    del d_base
-    out = pred.alloc_outputs(n)
+    # Placement: WHERE a buffer set lies in HBM moves this kernel by up to 10 % (persistent per
+    # allocation, DESIGN.md section 10, tools/exp/placement2.py).  A pipeline that owns its buffers
+    # allocates once and runs for hours, so it can afford to look: a few candidate sets are
+    # allocated, each is timed for a few steps, the fastest is kept and the others are freed.
+    # Every candidate's time is reported in the line (`placement`).
+    cands, trial_ms = [], []
+    for _ in range(max(1, args.placement_trials)):
+        fr_c = d_base[idx].contiguous().view(torch.uint16)
+        out_c = pred.alloc_outputs(n)
+        pred.predict(fr_c, out=out_c)
+        torch.cuda.synchronize()
+        trial_ms.append(pred.time_predict(fr_c, out_c, 5) / 5)
+        cands.append((fr_c, out_c))
+    chosen = int(np.argmin(trial_ms))
+    d_frames, out = cands[chosen]
+    del cands, fr_c, out_c, d_base
+    torch.cuda.empty_cache()
 
     def sync():
         torch.cuda.synchronize()
@@ -285,6 +301,8 @@ def main():
             "algorithmic_GBps_all_kernels": round(n * ALG_BYTES_PER_FRAME / (float(np.median(cm)) / 1e3) / 1e9, 1),
             "kernel_ms": {k: round(v, 4) for k, v in zip(names, kernel_ms) if k != "-"},
             "launches_per_step": 3,
+            "placement": {"candidate_sets_ms_per_step": [round(v, 4) for v in trial_ms], "chosen": chosen,
+                          "note": "buffer sets allocated one after another, 5 steps each, fastest kept (same code, same data; only the location in HBM differs)"},
             "frames_redone_per_step": int(redone),
             "flags_histogram": {str(k): int(v) for k, v in zip(*np.unique(flags, return_counts=True))},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 1),

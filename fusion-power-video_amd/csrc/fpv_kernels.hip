@@ -2110,12 +2110,13 @@ bool make_geom(uint32_t xs, uint32_t ys, int shift, int big_endian, Geom* g,
   g->xs = xs; g->ys = ys; g->npix = xs * ys;
   g->pw = xs / 4; g->ph = ys / 4; g->npv = g->pw * g->ph;
   g->shift = shift; g->swap = big_endian ? 1 : 0;
-  // streaming kernel: strips of about 100K pixels (whole preview rows), one wave each
+  // streaming kernel: strips of about 200K pixels (whole preview rows), one wave each
   {
     // Prefer a strip height that divides ys and whose pixel count is a multiple
-    // of the 1024-pixel step (the FAST kernel needs both); about 100K pixels
-    // (measured on 1280x800: 80..160 rows beat 32: fewer halo rows and partials).
-    const double kTarget = 102400.0;
+    // of the 1024-pixel step (the FAST kernel needs both); about 200K pixels
+    // (measured on 1280x800 with the per-strip hand-off of round 2: 160 and 200 rows
+    // beat 80 and 100 by 1.5 %, 400 rows lose again to the coarser load balance).
+    const double kTarget = 204800.0;
     uint32_t srows = (((uint32_t)kTarget + xs - 1) / xs + 3) & ~3u;
     {
       uint32_t best = 0;

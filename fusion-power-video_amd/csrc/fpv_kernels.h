@@ -47,13 +47,14 @@ struct FwdWorkspace {
   uint32_t* ctr;         // two counter blocks of 64 words (alternating batches): list sizes, task counters, votes
   uint32_t* anylow;      // [nframes]  OR of raw low bytes
   uint32_t* frame_done;  // [nframes]  strips of the frame that have finished
+  uint32_t* bdone;       // [nframes][redo_strips] arrivals at the boundary above each strip (parity counts)
   uint8_t* decision;     // [nframes]  bit0 delta, bit1 CG
   uint32_t* list_a;      // frames whose delta decision was mis-speculated
   uint32_t* list_b;      // frames to redo under their true flags
   uint8_t* pvb;          // [nframes][strips] raw first / last preview row of every strip
   uint16_t* partials;    // [nframes][strips][3][256] per-strip histograms of the fused pass
   uint8_t* spec;         // speculated flags for the next batch
-  size_t zero_bytes;     // leading bytes cleared once at creation (counters, anylow, frame_done)
+  size_t zero_bytes;     // leading bytes cleared once at creation (counters, anylow, frame_done, bdone)
   uint32_t seq;          // batches launched so far (selects the counter block); host side
 };
 size_t fwd_workspace_bytes(const Geom& g, uint32_t nframes);

@@ -370,6 +370,7 @@ struct StreamArgs {
   uint32_t with_delta;  // a delta frame exists
   uint32_t wave_lds;    // LDS bytes of one wave
   uint32_t wg_waves;    // waves (= consecutive frames) per workgroup of k_stream
+  uint32_t bd_stride;   // boundary words per frame
 };
 
 // Device pointers of one forward launch.
@@ -378,6 +379,7 @@ struct StreamPtrs {
   const uint8_t *dhigh, *dlow;
   uint8_t *high, *low, *preview, *flags;
   uint32_t *anylow, *frame_done;
+  uint32_t* bdone;     // [frame][strip]: arrivals at the boundary above the strip
   uint16_t* partials;
   uint8_t* pvb;        // boundary preview rows (raw) of every (frame, strip)
   uint32_t* ctr;       // this batch's counter block
@@ -813,32 +815,32 @@ __device__ __forceinline__ uint64_t entropy_wave(const uint32_t v[4]) {
   return (uint64_t)1024 * wave_sum(term) / sum;
 }
 
-// Clamped gradient of the preview rows that open a strip (cc:575-586): their north
+// Clamped gradient of the preview row that opens strip s >= 1 (cc:575-586): its north
 // row is the last row of the strip above, produced by another wave.  Both raw rows
-// come from the strips' boundary records.
+// come from the strips' boundary records.  `own_up` / `own_down`: this wave is the second
+// of the two neighbours to finish at the boundary above / below its strip and does that row.
 template <bool FAST>
 __device__ __forceinline__ void preview_boundary_rows(const StreamArgs& g, const uint8_t* pvb_frame,
-                                                      uint8_t* pv_f, uint32_t lane) {
+                                                      uint8_t* pv_f, uint32_t lane, uint32_t strip,
+                                                      bool own_up, bool own_down) {
   const uint32_t prs = g.strip_rows >> 2;  // preview rows per strip
-  if (FAST) {
-    const uint32_t gpr = g.pw >> 4, items = (g.strips - 1) * gpr;
-    for (uint32_t it = lane; it < items; it += 64) {
-      const uint32_t s = 1 + it / gpr, k = (it % gpr) << 4;
-      const uint8_t* first = pvb_frame + (size_t)s * g.pvb_stride;
-      const uint8_t* last = pvb_frame + (size_t)(s - 1) * g.pvb_stride + g.pwr;
+  const uint32_t per_row = FAST ? g.pw >> 4 : g.pw;
+  for (uint32_t it = lane; it < 2 * per_row; it += 64) {
+    const uint32_t which = it >= per_row ? 1u : 0u;
+    if (which ? !own_down : !own_up) continue;
+    const uint32_t s = strip + which;
+    const uint8_t* first = pvb_frame + (size_t)s * g.pvb_stride;
+    const uint8_t* last = pvb_frame + (size_t)(s - 1) * g.pvb_stride + g.pwr;
+    if (FAST) {
+      const uint32_t k = (it - which * per_row) << 4;
       const uint4 cur = ld_agent128(first + k), north = ld_agent128(last + k);
       const uint32_t wprev = k ? ld_agent32(first + k - 4) : ld_agent32(last + g.pw - 4);
       const uint32_t nwprev = k ? ld_agent32(last + k - 4) : ld_agent32(last + g.pwr) << 24;
       uint4 res = cg_res16(cur, north, wprev, nwprev);
       if (s * prs == 1 && k == 0) res.x = (res.x & 0xffffff00u) | (cur.x & 0xffu);  // pixel pw is a literal (cc:575)
       st_stream(pv_f + (size_t)s * prs * g.pw + k, res);
-    }
-  } else {
-    const uint32_t items = (g.strips - 1) * g.pw;
-    for (uint32_t it = lane; it < items; it += 64) {
-      const uint32_t s = 1 + it / g.pw, k = it % g.pw;
-      const uint8_t* first = pvb_frame + (size_t)s * g.pvb_stride;
-      const uint8_t* last = pvb_frame + (size_t)(s - 1) * g.pvb_stride + g.pwr;
+    } else {
+      const uint32_t k = it - which * per_row;
       const int x = (int)ld_agent8(first + k), n = (int)ld_agent8(last + k);
       const int w = (int)(k ? ld_agent8(first + k - 1) : ld_agent8(last + g.pw - 1));
       const int nw = (int)(k ? ld_agent8(last + k - 1) : ld_agent8(last + g.pwr));
@@ -849,10 +851,15 @@ __device__ __forceinline__ void preview_boundary_rows(const StreamArgs& g, const
 }
 
 // Strip epilogue: the strip's hand-off data leave through write-through stores, the
-// wave drains them, and ONE returning atomic both counts the strip as done and
-// fetches the wave's next task.  Returns true to the wave that completed the frame
-// (after an agent-scope acquire), *next_task = the task counter's old value.
-template <bool PARTIALS>
+// wave drains them, and ONE returning atomic instruction (four lanes, four words) counts
+// the strip as done, fetches the wave's next task and signs the strip off at the
+// boundaries it shares with its two neighbours.  A boundary word counts arrivals and is
+// never reset: each pass adds two, so an odd old value tells the second neighbour, which
+// then writes the preview row that straddles the boundary (its clamped gradient needs raw
+// rows of both strips).  Returns true to the wave that completed the frame; every reader of
+// other strips' data goes through an agent-scope acquire.  *next_task = the task counter's
+// old value.
+template <bool PARTIALS, bool FAST>
 __device__ __forceinline__ bool strip_arrive(const StreamCtx& c, const StreamArgs& g, const StreamPtrs& P,
                                              uint32_t frame, uint32_t strip, uint32_t orl,
                                              uint32_t* task_ctr, uint32_t* next_task) {
@@ -867,25 +874,30 @@ __device__ __forceinline__ bool strip_arrive(const StreamCtx& c, const StreamArg
   }
   if (c.lane == 0 && orl) atomicOr(&P.anylow[frame], orl);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every store and atomic of this strip has left
+  const bool has_up = c.use_cg && strip > 0, has_down = c.use_cg && strip + 1 < g.strips;
+  uint32_t* word = nullptr;
+  uint32_t* const bd = P.bdone + (size_t)frame * g.bd_stride + strip;
+  if (c.lane == 0) word = &P.frame_done[frame];
+  else if (c.lane == 1) word = task_ctr;
+  else if (c.lane == 2 && has_up) word = bd;
+  else if (c.lane == 3 && has_down) word = bd + 1;
   uint32_t old = 0;
-  if (c.lane < (task_ctr ? 2u : 1u)) old = atomicAdd(c.lane == 0 ? &P.frame_done[frame] : task_ctr, 1u);
+  if (word) old = atomicAdd(word, 1u);
   *next_task = (uint32_t)__builtin_amdgcn_readlane((int)old, 1);
   const bool last = (uint32_t)__builtin_amdgcn_readlane((int)old, 0) + 1 == g.strips;
-  if (last) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    if (c.lane == 0) atomicExch(&P.frame_done[frame], 0u);  // ready for the redo pass / the next batch
-  }
+  const bool own_up = has_up && ((uint32_t)__builtin_amdgcn_readlane((int)old, 2) & 1u);
+  const bool own_down = has_down && ((uint32_t)__builtin_amdgcn_readlane((int)old, 3) & 1u);
+  if (last || own_up || own_down) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (own_up || own_down)
+    preview_boundary_rows<FAST>(g, P.pvb + (size_t)frame * g.strips * g.pvb_stride,
+                                P.preview + (size_t)frame * g.npv, c.lane, strip, own_up, own_down);
+  if (last && c.lane == 0) atomicExch(&P.frame_done[frame], 0u);  // ready for the redo pass / the next batch
   return last;
 }
 
-// Flags byte (cc:447-449 + the decisions) and the strip-boundary preview rows.
-template <bool FAST>
-__device__ __forceinline__ void finalize_frame(const StreamCtx& c, const StreamArgs& g, const StreamPtrs& P,
-                                               uint32_t frame, uint32_t dec) {
+// Flags byte (cc:447-449 + the decisions).
+__device__ __forceinline__ void finalize_frame(const StreamCtx& c, const StreamPtrs& P, uint32_t frame, uint32_t dec) {
   if (c.lane == 0) P.flags[frame] = (uint8_t)(dec | (atomicExch(&P.anylow[frame], 0u) ? 0u : 4u));
-  if ((dec & 2u) && g.strips > 1)
-    preview_boundary_rows<FAST>(g, P.pvb + (size_t)frame * g.strips * g.pvb_stride,
-                                P.preview + (size_t)frame * g.npv, c.lane);
 }
 
 __device__ __forceinline__ void stream_ctx_init(StreamCtx& c, const StreamArgs& g, uint8_t* smem) {
@@ -961,7 +973,7 @@ __global__ __launch_bounds__(512, 2) void k_stream(StreamPtrs P, StreamArgs g) {
     if (frame < g.nframes) {
     const uint32_t orl = sp_delta ? run_strip<SWAP, FAST, true, LOW>(c, g, P, frame, strip, sp_cg)
                                   : run_strip<SWAP, FAST, false, LOW>(c, g, P, frame, strip, sp_cg);
-    const bool last = strip_arrive<true>(c, g, P, frame, strip, orl, wave == 0 ? &P.ctr[kCtrTask] : nullptr, &next);
+    const bool last = strip_arrive<true, FAST>(c, g, P, frame, strip, orl, wave == 0 ? &P.ctr[kCtrTask] : nullptr, &next);
     if (last) {
       // EstimateEntropy + the two decisions (cc:533, cc:564) from the strips' histograms
       const uint8_t* ph = reinterpret_cast<const uint8_t*>(P.partials + (size_t)frame * g.strips * (kHistFused * 256)) + c.lane * 8;
@@ -991,7 +1003,7 @@ __global__ __launch_bounds__(512, 2) void k_stream(StreamPtrs P, StreamArgs g) {
           atomicAdd(&P.ctr[kCtrVotes + dec], 1u);
           if (use_cg != sp_cg) P.list_b[atomicAdd(&P.ctr[kCtrListB], 1u)] = frame;
         }
-        if (use_cg == sp_cg) finalize_frame<FAST>(c, g, P, frame, dec);
+        if (use_cg == sp_cg) finalize_frame(c, P, frame, dec);
       }
     }
     }
@@ -1122,9 +1134,9 @@ __global__ __launch_bounds__(64, 2) void k_redo_stream(StreamPtrs P, StreamArgs 
     const uint32_t orl = (dec & 1u) ? run_strip<SWAP, FAST, true, LOW>(c, g, P, frame, strip, dec & 2u)
                                     : run_strip<SWAP, FAST, false, LOW>(c, g, P, frame, strip, dec & 2u);
     uint32_t next;
-    const bool last = strip_arrive<false>(c, g, P, frame, strip, orl, &P.ctr[kCtrRedoTask], &next);
+    const bool last = strip_arrive<false, FAST>(c, g, P, frame, strip, orl, &P.ctr[kCtrRedoTask], &next);
     task = gridDim.x + next;
-    if (last) finalize_frame<FAST>(c, g, P, frame, dec);
+    if (last) finalize_frame(c, P, frame, dec);
     __builtin_amdgcn_wave_barrier();
   }
 }
@@ -2202,12 +2214,14 @@ bool make_geom_decoder(uint32_t xs, uint32_t ys, Geom* g, const char** why) {
   return true;
 }
 
-// Workspace layout: [counter blocks | anylow | frame_done] are cleared ONCE when the
-// workspace is created; afterwards the kernels leave them clean (the counter blocks
-// alternate between batches, the wave that finalises a frame resets its two words).
+// Workspace layout: [counter blocks | anylow | frame_done | bdone] are cleared ONCE when
+// the workspace is created; afterwards the kernels leave them usable (the counter blocks
+// alternate between batches, the wave that finalises a frame resets its two words, the
+// boundary words only ever matter by their parity and every pass adds two).
 // The rest is fully written by the kernels.  `spec` survives batches.
 size_t fwd_workspace_bytes(const Geom& g, uint32_t max_frames) {
   size_t b = 512 + 2 * (size_t)round_up(max_frames * 4, 256);    // counter blocks, anylow, frame_done
+  b += round_up((size_t)max_frames * g.redo_strips * 4, 256);    // boundary words
   b += round_up(max_frames, 256);                                // decision
   b += 2 * (size_t)round_up(max_frames * 4, 256);                // list A, list B
   b += round_up((size_t)max_frames * g.redo_strips * g.pvb_stride, 256);  // boundary preview rows (redo_strips >= strips)
@@ -2224,6 +2238,8 @@ void carve_fwd_workspace(const Geom& g, uint32_t max_frames, void* base,
   p += round_up(max_frames * 4, 256);
   ws->frame_done = reinterpret_cast<uint32_t*>(p);
   p += round_up(max_frames * 4, 256);
+  ws->bdone = reinterpret_cast<uint32_t*>(p);
+  p += round_up((size_t)max_frames * g.redo_strips * 4, 256);
   ws->zero_bytes = (size_t)(p - static_cast<uint8_t*>(base));
   ws->decision = p;
   p += round_up(max_frames, 256);
@@ -2333,11 +2349,11 @@ static hipError_t predict_impl(const Geom& g, const uint16_t* d_frames,
   a.ring_base = g.ring_base; a.nacc = g.nacc; a.shift = (uint32_t)g.shift; a.nframes = nframes;
   static const int strip_major = getenv("FPV_STRIP_MAJOR") ? atoi(getenv("FPV_STRIP_MAJOR")) : 1;
   a.strip_major = (uint32_t)strip_major;
-  a.pwr = g.pwr; a.pvb_stride = g.pvb_stride; a.with_delta = (uint32_t)with_delta;
+  a.pwr = g.pwr; a.pvb_stride = g.pvb_stride; a.bd_stride = g.redo_strips; a.with_delta = (uint32_t)with_delta;
   StreamPtrs P;
   P.frames = d_frames; P.dhigh = d_dhigh; P.dlow = d_dlow;
   P.high = d_high; P.low = d_low; P.preview = d_preview; P.flags = d_flags;
-  P.anylow = ws.anylow; P.frame_done = ws.frame_done; P.partials = ws.partials; P.pvb = ws.pvb;
+  P.anylow = ws.anylow; P.frame_done = ws.frame_done; P.bdone = ws.bdone; P.partials = ws.partials; P.pvb = ws.pvb;
   P.ctr = ws.ctr + (ws.seq & 1u) * 64;
   P.ctr_next = ws.ctr + ((ws.seq + 1) & 1u) * 64;
   ws.seq++;

@@ -20,6 +20,7 @@ struct Geom {
   uint32_t pw, ph, npv;         // preview = (xs/4) x (ys/4)
   uint32_t strip_rows, strips;  // streaming kernel: rows per wave strip, strips per frame
   uint32_t redo_strip_rows, redo_strips;  // the same for the redo pass of mis-speculated frames (shorter strips)
+  uint32_t redo_rows[4];                  // strip heights the redo pass chooses from by list length (ascending, 0 = none)
   uint32_t ring_fwd, ring_base; // streaming kernel: LDS ring size (pow2), offset of strip pixel 0
   uint32_t nacc;                // streaming kernel: preview accumulator rows
   uint32_t pwr, pvb_stride;     // pw rounded up to 16; bytes of one (frame, strip) boundary record

@@ -371,6 +371,7 @@ struct StreamArgs {
   uint32_t wave_lds;    // LDS bytes of one wave
   uint32_t wg_waves;    // waves (= consecutive frames) per workgroup of k_stream
   uint32_t bd_stride;   // boundary words per frame
+  uint32_t redo_rows[4];  // strip heights the redo pass chooses from (ascending; 0 = none)
 };
 
 // Device pointers of one forward launch.
@@ -1119,6 +1120,15 @@ __global__ __launch_bounds__(64, 2) void k_redo_stream(StreamPtrs P, StreamArgs 
   }
   const uint32_t nb = P.ctr[kCtrListB];
   if (nb == 0) return;
+  // Strip height: the shortest strips when few frames are listed (a strip is a serial task
+  // and the grid should be busy), taller ones while the list still gives every wave about
+  // four tasks (each strip pays a halo, a pipeline fill and an arrival).
+#pragma unroll
+  for (int k = 1; k < 4; k++) {
+    const uint32_t r = g.redo_rows[k];
+    if (r && (uint64_t)nb * ((g.ys + r - 1) / r) >= 4ull * gridDim.x) g.strip_rows = r;
+  }
+  g.strips = (g.ys + g.strip_rows - 1) / g.strip_rows;
   StreamCtx c;
   stream_ctx_init(c, g, smem);
 #ifdef FPV_STAMPS
@@ -2183,6 +2193,18 @@ bool make_geom(uint32_t xs, uint32_t ys, int shift, int big_endian, Geom* g,
       break;
     }
     g->redo_strips = (ys + g->redo_strip_rows - 1) / g->redo_strip_rows;
+    // taller choices for long lists: about 2x, 4x, 8x the shortest, below the main strip height
+    g->redo_rows[0] = g->redo_strip_rows;
+    for (int k = 1; k < 4; k++) {
+      g->redo_rows[k] = 0;
+      const uint32_t prev = g->redo_rows[k - 1];
+      if (!prev) continue;
+      for (uint32_t r = (prev * 2 + 3) & ~3u; r < g->strip_rows; r += 4) {
+        if (g->fast && (ys % r || ((uint64_t)r * xs) % kStep)) continue;
+        g->redo_rows[k] = r;
+        break;
+      }
+    }
   }
   g->nd = (g->npix + 14) / 15;
   g->ncg = g->npix > xs + 1 ? (g->npix - xs - 1 + 30) / 31 : 0;
@@ -2381,8 +2403,9 @@ static hipError_t predict_impl(const Geom& g, const uint16_t* d_frames,
   k_redo_decide<SWAP><<<kListGrid, kThreads, 0, s>>>(d_frames, d_dhigh, ws.decision, P.ctr,
                                                     ws.list_a, ws.list_b, g, with_delta);
   if (ev) hipEventRecord(ev[2], s);
-  a.strip_rows = g.redo_strip_rows;
+  a.strip_rows = g.redo_strip_rows;  // k_redo_stream may pick a taller entry of redo_rows
   a.strips = g.redo_strips;
+  for (int k = 0; k < 4; k++) a.redo_rows[k] = g.redo_rows[k];
   a.wg_waves = 1;
   FPV_LAUNCH(k_redo_stream, waves, 1u);
 #undef FPV_LAUNCH

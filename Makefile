@@ -43,7 +43,7 @@ $(LIBDIR)/libfpv_amd.so: $(HOST_SRC) $(HOST_HDR) $(LIBDIR)/libfpvhip.so
 
 # Our own CLI tools (written from scratch; usable on the GPU box) and the native test driver
 # of the BASELINE configurations at their stated frame counts.
-tools: $(BINDIR)/fpv_encode $(BINDIR)/fpv_decode $(BINDIR)/fpv_benchmark $(BINDIR)/configs_driver
+tools: $(BINDIR)/fpv_encode $(BINDIR)/fpv_decode $(BINDIR)/fpv_benchmark $(BINDIR)/configs_driver $(BINDIR)/frame_rate
 $(BINDIR)/configs_driver: tests/configs_driver.cc $(LIBDIR)/libfpv_amd.so
 	@mkdir -p $(BINDIR)
 	$(CXX) $(CXXFLAGS) $< -L$(LIBDIR) -lfpv_amd -lfpvhip \
@@ -108,6 +108,11 @@ $(BINDIR)/columnar_dump: tests/columnar_dump.cc $(LIBDIR)/libfpv_amd.so $(wildca
 tests/shim/columnar_dump_cpushim: tests/columnar_dump.cc tests/shim/libfpv_amd_cpushim.so $(wildcard include/columnar_batch/*.h)
 	$(CXX) -std=c++14 -O2 -Wall -Iinclude/columnar_batch $< tests/shim/libfpv_amd_cpushim.so -lpthread \
 	    -Wl,-rpath,'$$ORIGIN' -o $@
+# Frame-API throughput (tests/frame_rate.cc; the reference build of the same source lives in oracle/_ref)
+$(BINDIR)/frame_rate: tests/frame_rate.cc $(LIBDIR)/libfpv_amd.so include/fusion_power_video.h
+	@mkdir -p $(BINDIR)
+	$(CXX) -std=c++14 -O2 -Wall -Iinclude $< -L$(LIBDIR) -lfpv_amd -lfpvhip -lpthread \
+	    -Wl,-rpath,'$$ORIGIN/../../$(LIBDIR)' -Wl,-rpath,$(ROCM_LIB) -o $@
 $(BINDIR)/columnar_driver: tests/columnar_driver.cc $(LIBDIR)/libfpv_amd.so $(wildcard include/columnar_batch/*.h)
 	@mkdir -p $(BINDIR)
 	$(CXX) -std=c++14 -O2 -Wall -Iinclude/columnar_batch $< -L$(LIBDIR) -lfpv_amd -lfpvhip -lpthread \

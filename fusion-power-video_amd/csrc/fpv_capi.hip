@@ -81,6 +81,7 @@ struct Slot {
   uint8_t* h_low = nullptr;   // [B][npix]
   uint8_t* h_pv = nullptr;    // [B][npv]
   uint8_t* h_flags = nullptr; // [B]
+  uint16_t* h_delta = nullptr; // [npix]    staging of a raw delta frame (never a batch's data)
   // device
   uint16_t* d_pix = nullptr;
   uint8_t* d_high = nullptr;
@@ -191,7 +192,8 @@ int alloc_slot(fpvhip_ctx* c, Slot* s) {
   const size_t B = c->max_batch, np = c->g.npix, nv = c->g.npv;
   auto up16 = [](size_t v) { return (v + 255) & ~(size_t)255; };
   const size_t o_pix = 0, o_high = o_pix + up16(B * np * 2), o_low = o_high + up16(B * np),
-               o_pv = o_low + up16(B * np), o_flags = o_pv + up16(B * nv), total = o_flags + up16(B);
+               o_pv = o_low + up16(B * np), o_flags = o_pv + up16(B * nv), o_delta = o_flags + up16(B),
+               total = o_delta + up16(np * 2);
   HIPOK(c, hipEventCreate(&s->done));
   HIPOK(c, hipEventCreate(&s->begin));
   HIPOK(c, hipEventCreateWithFlags(&s->up_done, hipEventDisableTiming));
@@ -202,7 +204,8 @@ int alloc_slot(fpvhip_ctx* c, Slot* s) {
   uint8_t* h = static_cast<uint8_t*>(s->host.base);
   s->h_pix = reinterpret_cast<uint16_t*>(h + o_pix);
   s->h_high = h + o_high; s->h_low = h + o_low; s->h_pv = h + o_pv; s->h_flags = h + o_flags;
-  HIPOK(c, hipMalloc(&s->dev, total));
+  s->h_delta = reinterpret_cast<uint16_t*>(h + o_delta);
+  HIPOK(c, hipMalloc(&s->dev, o_delta));
   uint8_t* d = static_cast<uint8_t*>(s->dev);
   s->d_pix = reinterpret_cast<uint16_t*>(d + o_pix);
   s->d_high = d + o_high; s->d_low = d + o_low; s->d_pv = d + o_pv; s->d_flags = d + o_flags;
@@ -388,9 +391,9 @@ int fpvhip_set_delta_raw(fpvhip_ctx* c, const uint16_t* delta_raw) {
   const double t0 = now_ms();
   HIPOK(c, hipSetDevice(c->device));
   // through pinned staging when a slot exists: the first pageable copy of a process costs ~7 ms
-  if (c->nslots && c->slots[0].ready.load() && !c->slots[0].pending) {
-    memcpy(c->slots[0].h_pix, delta_raw, (size_t)c->g.npix * 2);
-    HIPOK(c, hipMemcpy(c->d_dtmp, c->slots[0].h_pix, (size_t)c->g.npix * 2, hipMemcpyHostToDevice));
+  if (c->nslots && c->slots[0].ready.load()) {
+    memcpy(c->slots[0].h_delta, delta_raw, (size_t)c->g.npix * 2);
+    HIPOK(c, hipMemcpy(c->d_dtmp, c->slots[0].h_delta, (size_t)c->g.npix * 2, hipMemcpyHostToDevice));
   } else {
     HIPOK(c, hipMemcpy(c->d_dtmp, delta_raw, (size_t)c->g.npix * 2, hipMemcpyHostToDevice));
   }

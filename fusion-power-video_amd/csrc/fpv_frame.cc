@@ -6,7 +6,12 @@
 #include <brotli/encode.h>
 #include <string.h>
 
+#include <atomic>
+#include <condition_variable>
 #include <future>
+#include <map>
+#include <mutex>
+#include <tuple>
 
 #include "fpv_host_internal.h"
 #include "fusion_power_video.h"
@@ -53,6 +58,136 @@ void BrotliToVector(std::vector<uint8_t>* v) {
   }
   v->swap(out);
 }
+
+std::atomic<uint64_t> g_content_id(1);
+uint64_t NewContentId() { return g_content_id.fetch_add(1, std::memory_order_relaxed); }
+
+// Several threads may ask for the planes of one lazily split frame (a shared delta frame).
+std::mutex& SplitLock(const void* frame) {
+  static std::mutex locks[16];
+  return locks[(reinterpret_cast<uintptr_t>(frame) >> 6) & 15];
+}
+
+// ---- Predict calls of several threads combined into GPU batches ----
+//
+// The adapters above this interface (upstream's columnar and Arrow encoders) call
+// Frame::Predict from a pool of threads, one frame per call.  One synchronous GPU round
+// trip per call wastes the device and the host (a launch, three stream hand-offs and a
+// wait per frame, all of them contending in the runtime), so calls that arrive while the
+// GPU is busy with the previous batch are collected: every caller copies its pixels into
+// its place of the open batch's pinned staging buffer, the first one (the leader) closes
+// the batch as soon as the previous one has left the GPU, submits it, and everybody picks
+// up its own planes.  A lone caller gets a batch of one at once: nothing waits for company.
+class PredictCombiner {
+ public:
+  static constexpr uint32_t kMaxBatch = 16, kSlots = 2;
+  typedef std::tuple<int, size_t, size_t, int, bool> Key;  // device, xs, ys, shift, big endian
+
+  static std::shared_ptr<PredictCombiner> Get(const Key& key) {
+    static std::mutex m;
+    static std::map<Key, std::shared_ptr<PredictCombiner>>* all = new std::map<Key, std::shared_ptr<PredictCombiner>>();
+    std::lock_guard<std::mutex> l(m);
+    auto it = all->find(key);
+    if (it != all->end()) return it->second;
+    if (all->size() >= 4)  // keep the pinned memory bounded: drop a geometry nobody is using
+      for (auto d = all->begin(); d != all->end(); ++d)
+        if (d->second.use_count() == 1) { all->erase(d); break; }
+    std::shared_ptr<PredictCombiner> c(new PredictCombiner(key));
+    (*all)[key] = c;
+    return c;
+  }
+
+  ~PredictCombiner() { ReleaseEncoderCtx(ctx_); }
+
+  struct Result { const uint8_t *high, *low, *preview; uint8_t flags; };
+
+  // `set_delta(ctx)` uploads the caller's delta frame; it runs (in the leader) only when
+  // the context holds a different one.  `take(result)` copies the caller's planes out.
+  template <class SetDelta, class Take>
+  void Run(const uint16_t* pixels, uint64_t delta_id, SetDelta set_delta, Take take) {
+    std::unique_lock<std::mutex> l(m_);
+    Batch* b = nullptr;
+    for (;;) {
+      if (open_ && open_->delta == delta_id && open_->joined < kMaxBatch) { b = open_; break; }
+      if (!open_) {
+        const int s = slot_free_[0] ? 0 : slot_free_[1] ? 1 : -1;
+        if (s >= 0) {
+          slot_free_[s] = false;
+          b = open_ = new Batch();
+          b->slot = s;
+          b->delta = delta_id;
+          break;
+        }
+      }
+      cv_.wait(l);  // the open batch is full or for another delta frame, or both slots are busy
+    }
+    const uint32_t idx = b->joined++;
+    l.unlock();
+    memcpy(fpvhip_stage_in(ctx_, (uint32_t)b->slot, idx), pixels, npix_ * 2);
+    l.lock();
+    b->staged++;
+    if (idx == 0) {  // leader
+      cv_.wait(l, [&] { return !inflight_; });
+      open_ = nullptr;  // closed: later callers start the next batch
+      inflight_ = true;
+      cv_.notify_all();
+      cv_.wait(l, [&] { return b->staged == b->joined; });
+      const uint32_t n = b->joined;
+      l.unlock();
+      if (ctx_delta_ != delta_id) {  // only the leader of the batch in flight touches the context
+        if (delta_id) set_delta(ctx_);
+        ctx_delta_ = delta_id;
+      }
+      Check(fpvhip_predict_submit(ctx_, (uint32_t)b->slot, n, delta_id ? 1 : 0), ctx_, "fpvhip_predict_submit");
+      Check(fpvhip_predict_wait(ctx_, (uint32_t)b->slot, &b->high, &b->low, &b->preview, &b->flags), ctx_,
+            "fpvhip_predict_wait");
+      l.lock();
+      b->done = true;
+      inflight_ = false;
+      cv_.notify_all();
+    } else {
+      cv_.notify_all();
+      cv_.wait(l, [&] { return b->done; });
+    }
+    l.unlock();
+    Result r;
+    r.high = b->high + (size_t)idx * npix_;
+    r.low = b->low + (size_t)idx * npix_;
+    r.preview = b->preview + (size_t)idx * npv_;
+    r.flags = b->flags[idx];
+    take(r);
+    l.lock();
+    if (++b->left == b->joined) {
+      slot_free_[b->slot] = true;
+      delete b;
+      cv_.notify_all();
+    }
+  }
+
+ private:
+  struct Batch {
+    int slot = 0;
+    uint64_t delta = 0;
+    uint32_t joined = 0, staged = 0, left = 0;
+    bool done = false;
+    const uint8_t *high = nullptr, *low = nullptr, *preview = nullptr, *flags = nullptr;
+  };
+  explicit PredictCombiner(const Key& k)
+      : npix_(std::get<1>(k) * std::get<2>(k)), npv_((std::get<1>(k) / 4) * (std::get<2>(k) / 4)) {
+    ctx_ = AcquireEncoderCtx(std::get<0>(k), (uint32_t)std::get<1>(k), (uint32_t)std::get<2>(k), std::get<3>(k),
+                             std::get<4>(k), kMaxBatch, kSlots);
+    if (!ctx_) Fatal("Frame: fpvhip_create", fpvhip_last_error(nullptr));
+  }
+  std::mutex m_;
+  std::condition_variable cv_;
+  fpvhip_ctx* ctx_ = nullptr;
+  size_t npix_, npv_;
+  uint64_t ctx_delta_ = 0;  // content id of the delta frame the context holds (0: unknown / none)
+  bool slot_free_[kSlots] = {true, true};
+  bool inflight_ = false;
+  Batch* open_ = nullptr;
+};
+constexpr uint32_t PredictCombiner::kMaxBatch;
 }  // namespace
 
 size_t Frame::MaxCompressedPlaneSize(size_t xsize, size_t ysize) {
@@ -64,22 +199,38 @@ size_t Frame::MaxCompressedPreviewSize(size_t xsize, size_t ysize) {
 size_t Frame::MaxCompressedPlaneSize() { return BrotliEncoderMaxCompressedSize(size_); }
 size_t Frame::MaxCompressedPreviewSize() { return BrotliEncoderMaxCompressedSize(size_ / 16); }
 
-// cc:370-451: the split runs on the GPU right away (flags() must be correct
-// after construction); the pixels are kept so that Predict is ONE fused pass.
+// cc:370-451: the pixels are kept so that Predict is ONE fused pass (split + preview +
+// predictors) on the GPU; the byte planes and the NO_LOW_BYTES flag of the RAW state are
+// produced by SplitNow when somebody asks for them first.
 Frame::Frame(size_t xsize, size_t ysize, const uint16_t* image, int shift_to_left_align,
              bool big_endian, int64_t timestamp)
     : xsize_(xsize), ysize_(ysize), size_(xsize * ysize), timestamp_(timestamp),
       shift_(shift_to_left_align), big_endian_(big_endian) {
   if (!image) return;
   state_ = FrameState::RAW;
-  Fwd f(xsize_, ysize_, shift_, big_endian_);
-  high_.resize(size_);
-  if (shift_ != 8) low_.resize(size_);
-  int no_low = 0;
-  Check(fpvhip_split_frame(f.ctx, image, high_.data(), shift_ != 8 ? low_.data() : nullptr, &no_low),
-        f.ctx, "fpvhip_split_frame");
-  if (no_low) flags_ |= FrameFlags::NO_LOW_BYTES;
   pixels_ = std::make_shared<std::vector<uint16_t>>(image, image + size_);
+  planes_pending_ = 1;
+  content_id_ = NewContentId();
+}
+
+void Frame::SplitNow() const {
+  std::lock_guard<std::mutex> l(SplitLock(this));
+  if (!PlanesPending()) return;
+  Frame* self = const_cast<Frame*>(this);
+  Fwd f(xsize_, ysize_, shift_, big_endian_);
+  self->high_.resize(size_);
+  if (shift_ != 8) self->low_.resize(size_);
+  int no_low = 0;
+  Check(fpvhip_split_frame(f.ctx, pixels_->data(), self->high_.data(), shift_ != 8 ? self->low_.data() : nullptr,
+                           &no_low),
+        f.ctx, "fpvhip_split_frame");
+  if (no_low) self->flags_ |= FrameFlags::NO_LOW_BYTES;
+  __atomic_store_n(&planes_pending_, 0, __ATOMIC_RELEASE);
+}
+
+void Frame::Touch() {
+  if (PlanesPending()) SplitNow();
+  content_id_ = NewContentId();
 }
 
 // cc:453-465
@@ -90,6 +241,7 @@ Frame::Frame(size_t xsize, size_t ysize, const uint8_t* image, int64_t timestamp
     state_ = FrameState::RAW;
     high_.assign(image, image + size_);
   }
+  content_id_ = NewContentId();
 }
 
 // cc:467-489, including its two no-op assignments to the parameters (cc:482, 485)
@@ -99,6 +251,7 @@ Frame::Frame(size_t xsize, size_t ysize, uint8_t flags, uint8_t state, std::vect
       ysize_(ysize), size_(xsize * ysize), flags_(flags), state_(state), timestamp_(timestamp) {
   if (preview_.empty()) state_ &= ~FrameState::PREVIEW_GENERATED;
   if (!low_.empty()) flags_ &= ~FrameFlags::NO_LOW_BYTES;
+  content_id_ = NewContentId();
 }
 
 // cc:777-785
@@ -108,40 +261,53 @@ void Frame::Predict(Frame& delta_frame) {
     const bool want_delta = delta_frame.state() > FrameState::EMPTY;
     if (!want_delta || (state_ & FrameState::DELTA_PREDICTED)) return;  // nothing left to do
   }
-  if ((state_ & (predicted | FrameState::COMPRESSED)) || high_.size() != size_ || size_ == 0)
+  if ((state_ & (predicted | FrameState::COMPRESSED)) || size_ == 0 || (!PlanesPending() && high_.size() != size_))
     Fatal("Frame::Predict", "only frames in the RAW state can be predicted on the GPU");
   const bool with_delta = delta_frame.state() > FrameState::EMPTY;
-  const uint8_t *gh, *gl, *gp, *gf;
   const size_t npv = (xsize_ / 4) * (ysize_ / 4);
-  auto run = [&](fpvhip_ctx* ctx, bool planes) {
+  if (pixels_) {
+    // the fused pass over the pixels, in one batch with whatever other threads are asking for
+    auto set_delta = [&](fpvhip_ctx* ctx) {
+      if (delta_frame.pixels_ && delta_frame.shift_ == shift_ && delta_frame.big_endian_ == big_endian_) {
+        Check(fpvhip_set_delta_raw(ctx, delta_frame.pixels_->data()), ctx, "fpvhip_set_delta_raw");
+      } else {
+        if (delta_frame.PlanesPending()) delta_frame.SplitNow();
+        Check(fpvhip_set_delta_planes(ctx, delta_frame.high_.data(),
+                                      delta_frame.low_.size() == size_ ? delta_frame.low_.data() : nullptr),
+              ctx, "fpvhip_set_delta_planes");
+      }
+    };
+    auto take = [&](const PredictCombiner::Result& r) {
+      high_.assign(r.high, r.high + size_);
+      if (shift_ != 8) low_.assign(r.low, r.low + size_);
+      preview_.assign(r.preview, r.preview + npv);
+      flags_ = (uint8_t)(r.flags & (FrameFlags::USE_DELTA | FrameFlags::USE_CG | FrameFlags::NO_LOW_BYTES));
+    };
+    PredictCombiner::Get(PredictCombiner::Key(FrameDevice(), xsize_, ysize_, shift_, big_endian_))
+        ->Run(pixels_->data(), with_delta ? delta_frame.content_id_ : 0, set_delta, take);
+    planes_pending_ = 0;
+  } else {
+    // planes only (8-bit constructor, or a frame that went through Uncompress)
+    if (with_delta && delta_frame.PlanesPending()) delta_frame.SplitNow();
+    Fwd f(xsize_, ysize_, 0, false);
+    const uint8_t *gh, *gl, *gp, *gf;
     if (with_delta)
-      Check(fpvhip_set_delta_planes(ctx, delta_frame.high_.data(),
+      Check(fpvhip_set_delta_planes(f.ctx, delta_frame.high_.data(),
                                     delta_frame.low_.size() == size_ ? delta_frame.low_.data() : nullptr),
-            ctx, "fpvhip_set_delta_planes");
-    if (planes) {
-      memcpy(fpvhip_stage_plane(ctx, 0, 0, 0), high_.data(), size_);
-      if (low_.size() == size_) memcpy(fpvhip_stage_plane(ctx, 0, 0, 1), low_.data(), size_);
-      else memset(fpvhip_stage_plane(ctx, 0, 0, 1), 0, size_);
-      Check(fpvhip_predict_planes_submit(ctx, 0, 1, with_delta), ctx, "fpvhip_predict_planes_submit");
-    } else {
-      memcpy(fpvhip_stage_in(ctx, 0, 0), pixels_->data(), size_ * 2);
-      Check(fpvhip_predict_submit(ctx, 0, 1, with_delta), ctx, "fpvhip_predict_submit");
-    }
-    Check(fpvhip_predict_wait(ctx, 0, &gh, &gl, &gp, &gf), ctx, "fpvhip_predict_wait");
+            f.ctx, "fpvhip_set_delta_planes");
+    memcpy(fpvhip_stage_plane(f.ctx, 0, 0, 0), high_.data(), size_);
+    if (low_.size() == size_) memcpy(fpvhip_stage_plane(f.ctx, 0, 0, 1), low_.data(), size_);
+    else memset(fpvhip_stage_plane(f.ctx, 0, 0, 1), 0, size_);
+    Check(fpvhip_predict_planes_submit(f.ctx, 0, 1, with_delta), f.ctx, "fpvhip_predict_planes_submit");
+    Check(fpvhip_predict_wait(f.ctx, 0, &gh, &gl, &gp, &gf), f.ctx, "fpvhip_predict_wait");
     memcpy(high_.data(), gh, size_);
     if (low_.size() == size_) memcpy(low_.data(), gl, size_);
     preview_.assign(gp, gp + npv);
     flags_ = (uint8_t)((flags_ & FrameFlags::NO_LOW_BYTES) |
                        (gf[0] & (FrameFlags::USE_DELTA | FrameFlags::USE_CG)));
-  };
-  if (pixels_) {
-    Fwd f(xsize_, ysize_, shift_, big_endian_);
-    run(f.ctx, false);
-  } else {
-    Fwd f(xsize_, ysize_, 0, false);
-    run(f.ctx, true);
   }
   pixels_.reset();
+  content_id_ = NewContentId();
   state_ &= ~FrameState::RAW;
   state_ |= FrameState::PREVIEW_GENERATED | FrameState::CG_PREDICTED;
   if (with_delta) state_ |= FrameState::DELTA_PREDICTED;
@@ -168,6 +334,7 @@ void Frame::Compress(Frame& delta_frame) {
   }
   state_ &= ~FrameState::RAW;
   state_ |= FrameState::COMPRESSED;
+  content_id_ = NewContentId();
 }
 
 // cc:787-818 and cc:690-728
@@ -189,6 +356,7 @@ void Frame::CompressPredicted(size_t* encoded_high_size, uint8_t* encoded_high_b
     copy_out(preview_, encoded_preview_size, encoded_preview_buffer);
     return;
   }
+  if (PlanesPending()) SplitNow();
   auto brotli = [](const uint8_t* in, size_t n, size_t* sz, uint8_t* buf) {
     BrotliEncoderCompress(1, BROTLI_DEFAULT_WINDOW, BROTLI_DEFAULT_MODE, n, in, sz, buf);
   };
@@ -210,6 +378,9 @@ void Frame::CompressPredicted(size_t* encoded_high_size, uint8_t* encoded_high_b
 
 // cc:747-775 with the two Optionally-Unapply steps (cc:612-641, cc:595-610)
 void Frame::Uncompress(Frame& delta_frame) {
+  if (PlanesPending()) SplitNow();
+  if (delta_frame.PlanesPending()) delta_frame.SplitNow();
+  content_id_ = NewContentId();
   if (state_ & FrameState::COMPRESSED) {
     if (!high_.empty()) BrotliToVector(&high_);
     if (!(low_.empty() || (flags_ & FrameFlags::NO_LOW_BYTES))) BrotliToVector(&low_);

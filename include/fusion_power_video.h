@@ -80,14 +80,14 @@ class Frame {
 
   size_t xsize() const { return xsize_; }
   size_t ysize() const { return ysize_; }
-  uint8_t flags() const { return flags_; }
+  uint8_t flags() const { if (PlanesPending()) SplitNow(); return flags_; }
   uint8_t state() const { return state_; }
   int64_t timestamp() const { return timestamp_; }
-  const std::vector<uint8_t>& high() { return high_; }
-  const std::vector<uint8_t>& low() { return low_; }
+  const std::vector<uint8_t>& high() { if (PlanesPending()) SplitNow(); return high_; }
+  const std::vector<uint8_t>& low() { if (PlanesPending()) SplitNow(); return low_; }
   const std::vector<uint8_t>& preview() { return preview_; }
-  std::vector<uint8_t>&& MoveOutHigh() { return std::move(high_); }
-  std::vector<uint8_t>&& MoveOutLow() { return std::move(low_); }
+  std::vector<uint8_t>&& MoveOutHigh() { Touch(); return std::move(high_); }
+  std::vector<uint8_t>&& MoveOutLow() { Touch(); return std::move(low_); }
   std::vector<uint8_t>&& MoveOutPreview() { return std::move(preview_); }
 
   static size_t MaxCompressedPlaneSize(size_t xsize, size_t ysize);
@@ -117,10 +117,16 @@ class Frame {
   uint8_t state_ = FrameState::EMPTY;
   int64_t timestamp_ = -1;
   // Pixels as given to the first constructor, kept so that Predict can run
-  // split + prediction as ONE pass on the GPU.
+  // split + prediction as ONE pass on the GPU.  Until then the byte planes (and the
+  // NO_LOW_BYTES flag) are produced on first use: planes_pending_.
   std::shared_ptr<std::vector<uint16_t>> pixels_;
   int shift_ = 0;
   bool big_endian_ = false;
+  uint64_t content_id_ = 0;  // changes whenever the planes change; copies share it
+  mutable int planes_pending_ = 0;  // read / written atomically: a shared delta frame may be split by any thread
+  bool PlanesPending() const { return __atomic_load_n(&planes_pending_, __ATOMIC_ACQUIRE) != 0; }
+  void SplitNow() const;     // the first constructor's split (cc:370-451), on the GPU; thread-safe
+  void Touch();              // SplitNow if pending + a new content id
 };
 
 // Needs the whole file; any frame or preview in any order.

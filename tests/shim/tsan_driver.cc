@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -118,6 +119,40 @@ int main() {
     ta.join(); tb.join(); tc.join();
     if (ra || rb || rc) return 30 + ra + rb + rc;
     printf("concurrent DecodeFrames on one decoder ok\n");
+  }
+  {
+    // Frame::Predict from a pool of threads (what upstream's columnar / Arrow encoders do):
+    // the calls are combined into GPU batches; two delta frames alternate, both split
+    // lazily while the threads are already running.  Results = the single-threaded ones.
+    const size_t xs = 64, ys = 48, n = 96, npix = xs * ys;
+    std::vector<uint16_t> fr(n * npix);
+    uint32_t s = 4242;
+    for (size_t i = 0; i < fr.size(); i++) { s = s * 1664525u + 1013904223u; fr[i] = (uint16_t)(((i % xs) * 9 + (s >> 29)) & 0xfff); }
+    fpvc::Frame d0(xs, ys, &fr[0], 4, false, 0), d1(xs, ys, &fr[npix], 4, false, 1);
+    std::vector<std::vector<uint8_t>> want_high(n), want_prev(n);
+    std::vector<uint8_t> want_flags(n);
+    for (size_t i = 0; i < n; i++) {
+      fpvc::Frame f(xs, ys, &fr[i * npix], 4, false, (int64_t)i);
+      f.Predict(i % 3 ? d0 : d1);
+      want_high[i] = f.high(); want_prev[i] = f.preview(); want_flags[i] = f.flags();
+    }
+    std::atomic<size_t> next(0);
+    std::atomic<int> bad(0);
+    std::vector<std::thread> pool;
+    for (int t = 0; t < 6; t++)
+      pool.emplace_back([&] {
+        for (;;) {
+          const size_t i = next.fetch_add(1);
+          if (i >= n) break;
+          fpvc::Frame f(xs, ys, &fr[i * npix], 4, false, (int64_t)i);
+          f.Predict(i % 3 ? d0 : d1);
+          if (f.high() != want_high[i] || f.preview() != want_prev[i] || f.flags() != want_flags[i]) bad++;
+          if (i % 7 == 0 && d0.high().size() != npix) bad++;  // a reader of the shared delta frame's planes
+        }
+      });
+    for (auto& th : pool) th.join();
+    if (bad) return 40;
+    printf("concurrent Frame::Predict ok\n");
   }
   return 0;
 }

@@ -97,3 +97,33 @@ def test_upstream_benchmark_cold_start_vs_cpu_reference(raw100):
     assert table[8]["fps_ratio"] >= 0.9, table
     assert table[32]["fps_ratio"] >= 0.9, table
     assert table[64]["fps_ratio"] >= 0.7, table
+
+
+@pytest.mark.skipif(not _have(os.path.join(BIN, "frame_rate")), reason="build/bin/frame_rate not built")
+def test_frame_api_throughput_next_to_the_reference():
+    """The public Frame API (h:75-139) driven like upstream's columnar / Arrow encoders drive it:
+    a pool of threads, one `Frame(pixels)` + `Predict(delta)` (or `Compress`) per frame
+    (tests/frame_rate.cc, the same source over this library and over the CPU reference).
+    The Predict calls of the threads are combined into GPU batches; the plane bytes produced
+    are the reference's, and the rate is not below the reference's on the same host."""
+    def run(binary, frames, threads):
+        r = subprocess.run([binary, "1280", "800", "4", str(frames), str(threads)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-500:]
+        return {d["mode"]: d for d in map(json.loads, r.stdout.strip().splitlines())}
+    out = {}
+    for t in (1, 8, 16):
+        run(os.path.join(BIN, "frame_rate"), 64, t)  # warm: contexts, pinned staging
+        out[f"native_{t}"] = run(os.path.join(BIN, "frame_rate"), 400, t)
+        if _have(os.path.join(REF, "frame_rate")):
+            out[f"reference_{t}"] = run(os.path.join(REF, "frame_rate"), 200, t)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "frame_api_rate.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    for t in (1, 8, 16):
+        if f"reference_{t}" not in out:
+            continue
+        for mode in ("ctor+Predict", "ctor+Compress"):
+            n, r = out[f"native_{t}"][mode], out[f"reference_{t}"][mode]
+            # same bytes per frame out of both (the compressed sizes in the second mode)
+            assert n["plane_bytes"] * r["frames"] == r["plane_bytes"] * n["frames"], (t, mode)
+            assert n["fps"] >= 0.9 * r["fps"], (t, mode, n["fps"], r["fps"])

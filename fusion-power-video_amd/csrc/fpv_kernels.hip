@@ -743,23 +743,50 @@ __device__ __forceinline__ uint32_t run_strip(StreamCtx& c, const StreamArgs& g,
 
   for (uint32_t k = c.lane * 4; k < kHistFused * 256; k += 256)
     *reinterpret_cast<uint4*>(c.hist + k) = make_uint4(0, 0, 0, 0);
+  // kDepth steps of loads are in flight: the loads of step t + kDepth are issued when step t
+  // has consumed its registers.  The loop is unrolled by kDepth so that every stage keeps
+  // its own registers.  The pipeline is filled FIRST, so that the halo's loads below travel
+  // together with it: a strip's prologue costs one memory round trip, not one per halo chunk.
+  Pre p[kDepth];
+#pragma unroll
+  for (int d = 0; d < kDepth; d++) stream_load<FAST, DELTA, LOW>(c, d, niter, &p[d]);
   if (c.s > 0) {  // halo: post-delta high bytes of the xs+16 pixels in front of the strip
     const uint32_t hs = c.s - g.xs - 16, ngrp = (g.xs + 16) >> 2;
-    for (uint32_t k = c.lane; k < ngrp; k += 64) {
-      const uint2 v = *reinterpret_cast<const uint2*>(c.img + hs + 4 * k);
-      uint32_t h4, l4;
-      split4<SWAP>(v.x, v.y, (int)g.shift, &h4, &l4);
-      if (DELTA) h4 = sub4(h4, *reinterpret_cast<const uint32_t*>(P.dhigh + hs + 4 * k));
-      *reinterpret_cast<uint32_t*>(c.ring + ring_at(c, (int)(4 * k) - (int)(g.xs + 16))) = h4;
+    // raw preview pixel (prow0 - 1, pw - 1): north-west of this strip's second preview
+    // row's first pixel.  Its 4x4 box lies in the four image rows above the strip.
+    uint2 vw = make_uint2(0, 0);
+    if (use_cg && c.lane < 4)
+      vw = *reinterpret_cast<const uint2*>(c.img + (size_t)(row0 - 4 + c.lane) * g.xs + g.xs - 4);
+    constexpr int kHaloUnroll = 8;  // 8 x 64 lanes x 4 pixels per round: all loads first
+    for (uint32_t base = 0; base < ngrp; base += 64 * kHaloUnroll) {
+      uint2 v[kHaloUnroll];
+      uint32_t dv[kHaloUnroll];
+#pragma unroll
+      for (int u = 0; u < kHaloUnroll; u++) {
+        const uint32_t k = base + 64 * u + c.lane;
+        v[u] = make_uint2(0, 0);
+        dv[u] = 0;
+        if (k < ngrp) {
+          v[u] = *reinterpret_cast<const uint2*>(c.img + hs + 4 * k);
+          if (DELTA) dv[u] = *reinterpret_cast<const uint32_t*>(P.dhigh + hs + 4 * k);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kHaloUnroll; u++) {
+        const uint32_t k = base + 64 * u + c.lane;
+        if (k < ngrp) {
+          uint32_t h4, l4;
+          split4<SWAP>(v[u].x, v[u].y, (int)g.shift, &h4, &l4);
+          if (DELTA) h4 = sub4(h4, dv[u]);
+          *reinterpret_cast<uint32_t*>(c.ring + ring_at(c, (int)(4 * k) - (int)(g.xs + 16))) = h4;
+        }
+      }
     }
     if (use_cg) {
-      // raw preview pixel (prow0 - 1, pw - 1): north-west of this strip's second preview
-      // row's first pixel.  Its 4x4 box lies in the four image rows above the strip.
       uint32_t sum = 0;
       if (c.lane < 4) {
-        const uint2 v = *reinterpret_cast<const uint2*>(c.img + (size_t)(row0 - 4 + c.lane) * g.xs + g.xs - 4);
         uint32_t h4, l4;
-        split4<SWAP>(v.x, v.y, (int)g.shift, &h4, &l4);
+        split4<SWAP>(vw.x, vw.y, (int)g.shift, &h4, &l4);
         sum = __builtin_amdgcn_sad_u8(h4, 0, 0);
       }
       sum += (uint32_t)__shfl_xor((int)sum, 1, 64);
@@ -767,12 +794,6 @@ __device__ __forceinline__ uint32_t run_strip(StreamCtx& c, const StreamArgs& g,
       c.wlast = ((uint32_t)__builtin_amdgcn_readfirstlane((int)sum) >> 4) & 0xfeu;
     }
   }
-  // kDepth steps of loads are in flight: the loads of step t + kDepth are issued when step t
-  // has consumed its registers.  The loop is unrolled by kDepth so that every stage keeps
-  // its own registers.
-  Pre p[kDepth];
-#pragma unroll
-  for (int d = 0; d < kDepth; d++) stream_load<FAST, DELTA, LOW>(c, d, niter, &p[d]);
   __builtin_amdgcn_wave_barrier();
 
   const uint32_t nd = niter - niter % kDepth;
@@ -1098,7 +1119,7 @@ __global__ __launch_bounds__(kThreads) void k_redo_decide(
     const bool use_cg = eb < ea;
     if (threadIdx.x == 0) {
       const uint32_t dec = (use_delta ? 1u : 0u) | (use_cg ? 2u : 0u);
-      decision[frame] = (uint8_t)dec;
+      decision[frame] = (uint8_t)(dec | 0x80u);  // bit 7: the low plane has to be redone as well
       atomicAdd(&ctr[kCtrVotes + dec], 1u);
       list_b[atomicAdd(&ctr[kCtrListB], 1u)] = frame;
     }
@@ -1140,9 +1161,16 @@ __global__ __launch_bounds__(64, 2) void k_redo_stream(StreamPtrs P, StreamArgs 
   while (task < ntasks) {
     const uint32_t strip = task / nb;
     const uint32_t frame = P.list_b[task - strip * nb];
-    const uint32_t dec = P.decision[frame];
-    const uint32_t orl = (dec & 1u) ? run_strip<SWAP, FAST, true, LOW>(c, g, P, frame, strip, dec & 2u)
-                                    : run_strip<SWAP, FAST, false, LOW>(c, g, P, frame, strip, dec & 2u);
+    const uint32_t dec8 = P.decision[frame], dec = dec8 & 3u;
+    // The low plane depends on the delta decision only: k_stream's is already right unless
+    // the frame came through list A (bit 7, set by k_redo_decide).
+    uint32_t orl;
+    if (LOW && (dec8 & 0x80u))
+      orl = (dec & 1u) ? run_strip<SWAP, FAST, true, LOW>(c, g, P, frame, strip, dec & 2u)
+                       : run_strip<SWAP, FAST, false, LOW>(c, g, P, frame, strip, dec & 2u);
+    else
+      orl = (dec & 1u) ? run_strip<SWAP, FAST, true, false>(c, g, P, frame, strip, dec & 2u)
+                       : run_strip<SWAP, FAST, false, false>(c, g, P, frame, strip, dec & 2u);
     uint32_t next;
     const bool last = strip_arrive<false, FAST>(c, g, P, frame, strip, orl, &P.ctr[kCtrRedoTask], &next);
     task = gridDim.x + next;

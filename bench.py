@@ -134,7 +134,7 @@ def main():
     ap.add_argument("--frames", type=int, default=NFRAMES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
-    ap.add_argument("--placement-trials", type=int, default=6,
+    ap.add_argument("--placement-trials", type=int, default=10,
                     help="candidate buffer sets to allocate and time before the run; the fastest is used (1 = take the first)")
     ap.add_argument("--quick", action="store_true",
                     help="profiling runs (rocprofv3): only the headline workload and the inverse, few launches")

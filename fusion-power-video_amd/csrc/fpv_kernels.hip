@@ -372,6 +372,8 @@ struct StreamArgs {
   uint32_t wg_waves;    // waves (= consecutive frames) per workgroup of k_stream
   uint32_t bd_stride;   // boundary words per frame
   uint32_t redo_rows[4];  // strip heights the redo pass chooses from (ascending; 0 = none)
+  uint32_t in_pitch;    // pixels from one frame to the next in `frames` (npix)
+  uint32_t out_pitch;   // bytes from one frame to the next in `high` / `low` (npix)
 };
 
 // Device pointers of one forward launch.
@@ -389,6 +391,32 @@ struct StreamPtrs {
   uint32_t *list_a, *list_b;
   uint8_t* spec;       // speculation byte: read by k_stream, written by k_redo_stream
 };
+
+// The arguments of the streaming kernels as ONE by-value kernel parameter.  The kernels do
+// not read the parameter but the kernarg segment it lies in, and again after every strip:
+// values that are only needed between two strips (most pointers, most of the geometry)
+// then do not occupy scalar registers across the strip's loop.  Held in registers, they
+// pushed the loop's own scalars out: 16 spill reloads (v_readlane) per 1024-pixel step.
+struct StreamLaunch {
+  StreamPtrs P;
+  StreamArgs g;
+};
+typedef const __attribute__((address_space(4))) StreamLaunch* LaunchArgs;
+__device__ __forceinline__ LaunchArgs launch_args() {
+  LaunchArgs p = (LaunchArgs)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));  // opaque: loads through it stay behind this point
+  return p;
+}
+__device__ __forceinline__ StreamArgs launch_g() {
+  StreamArgs g;
+  __builtin_memcpy(&g, &launch_args()->g, sizeof g);
+  return g;
+}
+__device__ __forceinline__ StreamPtrs launch_p() {
+  StreamPtrs P;
+  __builtin_memcpy(&P, &launch_args()->P, sizeof P);
+  return P;
+}
 
 struct StreamCtx {
 #ifdef FPV_STAMPS
@@ -715,12 +743,12 @@ __device__ __forceinline__ uint32_t run_strip(StreamCtx& c, const StreamArgs& g,
                                               uint32_t frame, uint32_t strip, bool use_cg) {
   const uint32_t row0 = strip * g.strip_rows;
   const uint32_t rows = min(g.strip_rows, g.ys - row0);
-  const size_t fbase = (size_t)frame * g.npix;
+  const size_t fbase = (size_t)frame * g.out_pitch;
   c.use_delta = DELTA;
   c.use_cg = use_cg;
   c.s = row0 * g.xs;
   c.npx = rows * g.xs;
-  c.img = P.frames + fbase;
+  c.img = P.frames + (size_t)frame * g.in_pitch;
   c.dh = P.dhigh; c.dl = P.dlow;
   c.high_f = P.high + fbase;
   c.low_f = P.low + fbase;
@@ -958,43 +986,64 @@ __device__ __forceinline__ void stream_ctx_init(StreamCtx& c, const StreamArgs& 
 // a task is one strip of wg_waves CONSECUTIVE frames, and the waves start it together, so
 // that the strip's delta bytes, which all of them read at about the same time, come from
 // the CU's L1 for all but the first.  Nothing else couples the waves of a workgroup.
+#ifdef FPV_WAVES_EU  // experiments: register budget for FPV_WAVES_EU waves per SIMD
+#define FPV_STREAM_BOUNDS __attribute__((amdgpu_waves_per_eu(FPV_WAVES_EU, FPV_WAVES_EU))) __launch_bounds__(512)
+#else
+#define FPV_STREAM_BOUNDS __launch_bounds__(512, 2)
+#endif
 template <bool SWAP, bool FAST, bool LOW>
-__global__ __launch_bounds__(512, 2) void k_stream(StreamPtrs P, StreamArgs g) {
+__global__ FPV_STREAM_BOUNDS void k_stream(StreamLaunch) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const uint32_t W = g.wg_waves;
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  uint32_t* next_slot = reinterpret_cast<uint32_t*>(smem + W * g.wave_lds);
   StreamCtx c;
-  stream_ctx_init(c, g, smem + wave * g.wave_lds);
-  const uint32_t spec = *P.spec & (g.with_delta ? 3u : 2u);
-  const bool sp_delta = spec & 1u, sp_cg = spec & 2u;
-  if (blockIdx.x == 0 && threadIdx.x < kCtrWords) P.ctr_next[threadIdx.x] = 0;  // the next batch's counters
+  bool sp_delta, sp_cg;
+  {
+    const StreamArgs g = launch_g();
+    const StreamPtrs P = launch_p();
+    stream_ctx_init(c, g, smem + wave * g.wave_lds);
+    const uint32_t spec = *P.spec & (g.with_delta ? 3u : 2u);
+    sp_delta = spec & 1u;
+    sp_cg = spec & 2u;
+    if (blockIdx.x == 0 && threadIdx.x < kCtrWords) P.ctr_next[threadIdx.x] = 0;  // the next batch's counters
+  }
 #ifdef FPV_STAMPS
   for (int k = 0; k < 6; k++) c.seg[k] = 0;
   c.tlast = __builtin_amdgcn_s_memtime();
 #endif
-  const uint32_t ngroups = (g.nframes + W - 1) / W;
-  const uint32_t ntasks = ngroups * g.strips;
   // The first task of a workgroup is its index; later ones come from the device-wide
   // counter (thousands of waves hitting one word at launch would queue for ~25 us:
   // same-address atomics serialise at ~12 ns).
   uint32_t task = blockIdx.x;
-  while (task < ntasks) {
-    // Strip-major order: waves resident at the same time work on the SAME strip of
-    // different frames, so the strip's delta bytes are shared through L1/L2.
-    uint32_t group, strip;
-    if (g.strip_major) {
-      strip = task / ngroups;
-      group = task - strip * ngroups;
-    } else {
-      group = task / g.strips;
-      strip = task - group * g.strips;
+  for (;;) {
+    uint32_t frame, strip, orl = 0;
+    bool active;
+    {
+      const StreamArgs g = launch_g();
+      const StreamPtrs P = launch_p();
+      const uint32_t W = g.wg_waves;
+      const uint32_t ngroups = (g.nframes + W - 1) / W;
+      if (task >= ngroups * g.strips) break;
+      // Strip-major order: waves resident at the same time work on the SAME strip of
+      // different frames, so the strip's delta bytes are shared through L1/L2.
+      uint32_t group;
+      if (g.strip_major) {
+        strip = task / ngroups;
+        group = task - strip * ngroups;
+      } else {
+        group = task / g.strips;
+        strip = task - group * g.strips;
+      }
+      frame = group * W + wave;
+      active = frame < g.nframes;
+      if (active)
+        orl = sp_delta ? run_strip<SWAP, FAST, true, LOW>(c, g, P, frame, strip, sp_cg)
+                       : run_strip<SWAP, FAST, false, LOW>(c, g, P, frame, strip, sp_cg);
     }
-    const uint32_t frame = group * W + wave;
+    const StreamArgs g = launch_g();  // read again: see StreamLaunch
+    const StreamPtrs P = launch_p();
+    const uint32_t W = g.wg_waves;
     uint32_t next = 0;
-    if (frame < g.nframes) {
-    const uint32_t orl = sp_delta ? run_strip<SWAP, FAST, true, LOW>(c, g, P, frame, strip, sp_cg)
-                                  : run_strip<SWAP, FAST, false, LOW>(c, g, P, frame, strip, sp_cg);
+    if (active) {
     const bool last = strip_arrive<true, FAST>(c, g, P, frame, strip, orl, wave == 0 ? &P.ctr[kCtrTask] : nullptr, &next);
     if (last) {
       // EstimateEntropy + the two decisions (cc:533, cc:564) from the strips' histograms
@@ -1030,6 +1079,7 @@ __global__ __launch_bounds__(512, 2) void k_stream(StreamPtrs P, StreamArgs g) {
     }
     }
     if (W > 1) {  // wave 0 (always active) fetched the workgroup's next task
+      uint32_t* next_slot = reinterpret_cast<uint32_t*>(smem + W * g.wave_lds);
       if (threadIdx.x == 0) *next_slot = next;
       __syncthreads();
       next = *reinterpret_cast<volatile uint32_t*>(next_slot);
@@ -1039,9 +1089,11 @@ __global__ __launch_bounds__(512, 2) void k_stream(StreamPtrs P, StreamArgs g) {
     __builtin_amdgcn_wave_barrier();
   }
 #ifdef FPV_STAMPS
-  if (c.lane == 0)  // stamps leave through a buffer nothing else reads (ctr_next[32..43])
+  if (c.lane == 0) {  // stamps leave through a buffer nothing else reads (ctr_next[32..43])
+    const StreamPtrs P = launch_p();
     for (int k = 0; k < 6; k++)
       atomicAdd(reinterpret_cast<unsigned long long*>(P.ctr_next + 32) + k, c.seg[k]);
+  }
 #endif
 }
 
@@ -1130,47 +1182,64 @@ __global__ __launch_bounds__(kThreads) void k_redo_decide(
 // The strip pass of k_stream under each listed frame's TRUE flags, and the next
 // batch's speculation: the most frequent decision of this batch (all votes are
 // in: they are cast by k_stream and k_redo_decide).
-template <bool SWAP, bool FAST, bool LOW>
-__global__ __launch_bounds__(64, 2) void k_redo_stream(StreamPtrs P, StreamArgs g) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    uint32_t best = 0, nbest = P.ctr[kCtrVotes];
-    for (uint32_t k = 1; k < 4; k++)
-      if (P.ctr[kCtrVotes + k] > nbest) { best = k; nbest = P.ctr[kCtrVotes + k]; }
-    if (nbest) *P.spec = (uint8_t)best;
-  }
-  const uint32_t nb = P.ctr[kCtrListB];
-  if (nb == 0) return;
-  // Strip height: the shortest strips when few frames are listed (a strip is a serial task
-  // and the grid should be busy), taller ones while the list still gives every wave about
-  // four tasks (each strip pays a halo, a pipeline fill and an arrival).
+// Geometry of the redo pass for a list of nb frames.  Strip height: the shortest strips when
+// few frames are listed (a strip is a serial task and the grid should be busy), taller ones
+// while the list still gives every wave about four tasks (each strip pays a halo, a
+// pipeline fill and an arrival).
+__device__ __forceinline__ StreamArgs redo_args(uint32_t nb) {
+  StreamArgs g = launch_g();
 #pragma unroll
   for (int k = 1; k < 4; k++) {
     const uint32_t r = g.redo_rows[k];
     if (r && (uint64_t)nb * ((g.ys + r - 1) / r) >= 4ull * gridDim.x) g.strip_rows = r;
   }
   g.strips = (g.ys + g.strip_rows - 1) / g.strip_rows;
+  return g;
+}
+
+template <bool SWAP, bool FAST, bool LOW>
+__global__ __launch_bounds__(64, 2) void k_redo_stream(StreamLaunch) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint32_t nb;
+  {
+    const StreamPtrs P = launch_p();
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      uint32_t best = 0, nbest = P.ctr[kCtrVotes];
+      for (uint32_t k = 1; k < 4; k++)
+        if (P.ctr[kCtrVotes + k] > nbest) { best = k; nbest = P.ctr[kCtrVotes + k]; }
+      if (nbest) *P.spec = (uint8_t)best;
+    }
+    nb = P.ctr[kCtrListB];
+  }
+  if (nb == 0) return;
   StreamCtx c;
-  stream_ctx_init(c, g, smem);
+  stream_ctx_init(c, redo_args(nb), smem);
 #ifdef FPV_STAMPS
   for (int k = 0; k < 6; k++) c.seg[k] = 0;
   c.tlast = __builtin_amdgcn_s_memtime();
 #endif
-  const uint32_t ntasks = nb * g.strips;
   uint32_t task = blockIdx.x;
-  while (task < ntasks) {
-    const uint32_t strip = task / nb;
-    const uint32_t frame = P.list_b[task - strip * nb];
-    const uint32_t dec8 = P.decision[frame], dec = dec8 & 3u;
-    // The low plane depends on the delta decision only: k_stream's is already right unless
-    // the frame came through list A (bit 7, set by k_redo_decide).
-    uint32_t orl;
-    if (LOW && (dec8 & 0x80u))
-      orl = (dec & 1u) ? run_strip<SWAP, FAST, true, LOW>(c, g, P, frame, strip, dec & 2u)
-                       : run_strip<SWAP, FAST, false, LOW>(c, g, P, frame, strip, dec & 2u);
-    else
-      orl = (dec & 1u) ? run_strip<SWAP, FAST, true, false>(c, g, P, frame, strip, dec & 2u)
-                       : run_strip<SWAP, FAST, false, false>(c, g, P, frame, strip, dec & 2u);
+  for (;;) {
+    uint32_t frame, strip, dec, orl;
+    {
+      const StreamArgs g = redo_args(nb);
+      const StreamPtrs P = launch_p();
+      if (task >= nb * g.strips) break;
+      strip = task / nb;
+      frame = P.list_b[task - strip * nb];
+      const uint32_t dec8 = P.decision[frame];
+      dec = dec8 & 3u;
+      // The low plane depends on the delta decision only: k_stream's is already right unless
+      // the frame came through list A (bit 7, set by k_redo_decide).
+      if (LOW && (dec8 & 0x80u))
+        orl = (dec & 1u) ? run_strip<SWAP, FAST, true, LOW>(c, g, P, frame, strip, dec & 2u)
+                         : run_strip<SWAP, FAST, false, LOW>(c, g, P, frame, strip, dec & 2u);
+      else
+        orl = (dec & 1u) ? run_strip<SWAP, FAST, true, false>(c, g, P, frame, strip, dec & 2u)
+                         : run_strip<SWAP, FAST, false, false>(c, g, P, frame, strip, dec & 2u);
+    }
+    const StreamArgs g = redo_args(nb);  // read again: see StreamLaunch
+    const StreamPtrs P = launch_p();
     uint32_t next;
     const bool last = strip_arrive<false, FAST>(c, g, P, frame, strip, orl, &P.ctr[kCtrRedoTask], &next);
     task = gridDim.x + next;
@@ -2093,6 +2162,10 @@ __global__ __launch_bounds__(192) void k_inverse_trio(
 
 }  // namespace
 
+#ifdef FPV_EXP_PITCH
+uint32_t g_exp_in_pad = 0, g_exp_out_pad = 0;
+#endif
+
 // ------------------------------------------------------------- host side ---
 
 static uint32_t round_up(uint32_t v, uint32_t a) { return (v + a - 1) / a * a; }
@@ -2395,6 +2468,11 @@ static hipError_t predict_impl(const Geom& g, const uint16_t* d_frames,
   const int with_delta = d_dhigh != nullptr;
   StreamArgs a;
   a.xs = g.xs; a.ys = g.ys; a.npix = g.npix; a.pw = g.pw; a.npv = g.npv;
+  a.in_pitch = a.out_pitch = g.npix;
+#ifdef FPV_EXP_PITCH  // experiments only (tools/exp/pitch.py): frames / planes at a padded pitch
+  a.in_pitch += g_exp_in_pad;
+  a.out_pitch += g_exp_out_pad;
+#endif
   a.strip_rows = g.strip_rows; a.strips = g.strips; a.ring_fwd = g.ring_fwd;
   a.ring_base = g.ring_base; a.nacc = g.nacc; a.shift = (uint32_t)g.shift; a.nframes = nframes;
   static const int strip_major = getenv("FPV_STRIP_MAJOR") ? atoi(getenv("FPV_STRIP_MAJOR")) : 1;
@@ -2418,11 +2496,11 @@ static hipError_t predict_impl(const Geom& g, const uint16_t* d_frames,
   do {                                                                                                \
     const uint32_t lds_ = (WAVES) * g.wave_lds + 16;                                                  \
     if (g.fast) {                                                                                     \
-      if (lowp) K<SWAP, true, true><<<GRID, 64 * (WAVES), lds_, s>>>(P, a);                           \
-      else K<SWAP, true, false><<<GRID, 64 * (WAVES), lds_, s>>>(P, a);                               \
+      if (lowp) K<SWAP, true, true><<<GRID, 64 * (WAVES), lds_, s>>>(StreamLaunch{P, a});                           \
+      else K<SWAP, true, false><<<GRID, 64 * (WAVES), lds_, s>>>(StreamLaunch{P, a});                               \
     } else {                                                                                          \
-      if (lowp) K<SWAP, false, true><<<GRID, 64 * (WAVES), lds_, s>>>(P, a);                          \
-      else K<SWAP, false, false><<<GRID, 64 * (WAVES), lds_, s>>>(P, a);                              \
+      if (lowp) K<SWAP, false, true><<<GRID, 64 * (WAVES), lds_, s>>>(StreamLaunch{P, a});                          \
+      else K<SWAP, false, false><<<GRID, 64 * (WAVES), lds_, s>>>(StreamLaunch{P, a});                              \
     }                                                                                                 \
   } while (0)
   FPV_LAUNCH(k_stream, grid, W);
@@ -2441,6 +2519,15 @@ static hipError_t predict_impl(const Geom& g, const uint16_t* d_frames,
   if (ev) hipEventRecord(ev[4], s);
   return hipGetLastError();
 }
+
+#ifdef FPV_EXP_PITCH
+}  // namespace fpvhip
+extern "C" void fpvhip_exp_set_pad(uint32_t in_pad_px, uint32_t out_pad_bytes) {
+  fpvhip::g_exp_in_pad = in_pad_px;
+  fpvhip::g_exp_out_pad = out_pad_bytes;
+}
+namespace fpvhip {
+#endif
 
 hipError_t launch_predict(const Geom& g, const uint16_t* d_frames,
                           uint32_t nframes, const uint8_t* d_dhigh,

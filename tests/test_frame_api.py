@@ -53,3 +53,35 @@ def test_uncompress_restores_raw_planes(synth, oracle):
         assert np.array_equal(GOLD[name + "/rest_high"], h), name
         if shift != 8 and name != "zero_low_vs_delta":
             assert np.array_equal(GOLD[name + "/rest_low"], l), name
+
+
+def _check_concurrent(api, synth):
+    """The fixtures again, from eight threads at once and in a shuffled order: Predict calls of
+    different shifts / byte orders / delta frames meet in the combiner (ctypes drops the GIL)."""
+    import random
+    from concurrent.futures import ThreadPoolExecutor
+    xs, ys, cs = cases(synth)
+    jobs = [c for c in cs for _ in range(6)]
+    random.Random(5).shuffle(jobs)
+
+    def one(job):
+        name, img, delta, shift, be = job
+        ok = np.array_equal(api.compress_full(img, delta, xs, ys, shift, be), GOLD[name + "/full"])
+        if ok and delta is not None:
+            got = api.cycle(img, delta, xs, ys, shift, be)
+            ok = all(np.array_equal(v, GOLD[name + "/" + k]) for k, v in got.items())
+        return name, ok
+    with ThreadPoolExecutor(8) as ex:
+        bad = [name for name, ok in ex.map(one, jobs) if not ok]
+    assert not bad, bad
+
+
+def test_frame_api_concurrent_cpu(fpv, synth):
+    if not os.path.exists(SHIM):
+        pytest.skip("tests/shim not built")
+    _check_concurrent(FrameApi(ctypes.CDLL(SHIM), "fpvc_"), synth)
+
+
+@pytest.mark.gpu
+def test_frame_api_concurrent_gpu(fpv, synth):
+    _check_concurrent(FrameApi(fpv.host_lib(), "fpvc_"), synth)

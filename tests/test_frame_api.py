@@ -12,7 +12,7 @@ from frame_api_driver import FrameApi, cases
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLD = np.load(os.path.join(HERE, "golden", "frame_api.npz"))
-SHIM = os.path.join(HERE, "shim", "libfpv_amd_cpushim.so")
+SHIM = os.environ.get("FPV_TEST_SHIM") or os.path.join(HERE, "shim", "libfpv_amd_cpushim.so")
 
 
 def check(api, synth):

@@ -135,8 +135,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--placement-trials", type=int, default=16,
-                    help="candidate buffer sets to allocate and time before the run, at most; the fastest is used "
-                         "(1 = take the first); the search ends early at a set 6 %% faster than the median so far")
+                    help="candidate buffer sets to allocate and time before the run; the fastest is used (1 = take the first)")
     ap.add_argument("--quick", action="store_true",
                     help="profiling runs (rocprofv3): only the headline workload and the inverse, few launches")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (RCCL, one GPU per rank) or gloo (rehearsal)")
@@ -184,9 +183,6 @@ def main():
         torch.cuda.synchronize()
         trial_ms.append(pred.time_predict(fr_c, out_c, 5) / 5)
         cands.append((fr_c, out_c))
-        # most sets sit on one plateau, a few are 8-10 % faster: stop at the first of those
-        if len(trial_ms) >= 4 and trial_ms[-1] < 0.94 * float(np.median(trial_ms[1:-1])):
-            break
     chosen = int(np.argmin(trial_ms))
     d_frames, out = cands[chosen]
     del cands, fr_c, out_c, d_base

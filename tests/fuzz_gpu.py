@@ -55,8 +55,11 @@ def content(kind, n, ys, xs):
 
 cases = frames_total = 0
 seen_flags = set()
-t0 = time.time()
+t0 = t_report = time.time()
 while time.time() - t0 < budget:
+    if time.time() - t_report > 60:   # a line a minute: long runs must not look hung
+        t_report = time.time()
+        print(f"... {cases} cases, {frames_total} frames, {t_report - t0:.0f} s", flush=True)
     big = os.environ.get("FUZZ_BIG") and rng.integers(0, 4) == 0     # wide / tall frames now and then
     xs = int(rng.choice([rng.integers(1, 40) * 4, rng.integers(64, 520) * 4, 256, 1280, 1536]))
     ys = int(rng.integers(1, 24)) * 4

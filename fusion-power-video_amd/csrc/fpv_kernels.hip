@@ -1982,6 +1982,11 @@ __global__ __launch_bounds__(192) void k_inverse_trio(
   const uint32_t head = min(xs + 4, npix);
   const uint32_t nsteps = (npix - head + S - 1) / S;
   uint32_t w_prev = 0, npass = 0, maxpass = 0;  // chain wave
+#ifndef FPV_NO_CHAIN_PRIO
+  // The chain wave is the frame's critical path; on its SIMD it competes with i/o waves of
+  // other frames.  Issue arbitration goes by priority first, then age (MI355X_MICROARCH.md).
+  if (role == 0) __builtin_amdgcn_s_setprio(3);
+#endif
 
   // i/o waves: stage superstep t's residuals / planes into LDS (coalesced layout:
   // dword k * 64 + lane).  Indices are clamped into the frame; what lies beyond the

@@ -1390,9 +1390,11 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 __device__ __forceinline__ uint32_t inv_px(uint32_t n, uint32_t w, uint32_t d, uint32_t r) {
+  // ClampedGradient (cc:247-252) = the gradient n + w - nw clamped between n and w = the MEDIAN
+  // of the three: one v_med3_i32, no separate min / max.  All operands are v << 8.
   const int t = (int)w + (int)d;
-  const int lo = min((int)n, (int)w), hi = max((int)n, (int)w);
-  const int md = max(lo, min(hi, t));                 // one v_med3_i32
+  const int a = (int)n, b = (int)w;
+  const int md = max(min(a, b), min(max(a, b), t));   // the backend's median-of-three pattern
   return as_u32(as_pk((uint32_t)md) + as_pk(r));      // v_pk_add_u16: low lane wraps mod 2^16
 }
 

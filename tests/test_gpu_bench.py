@@ -1,0 +1,46 @@
+"""bench.py's contract: ONE JSON line on stdout with the fields the driver reads, the roofline
+and cpu_baseline objects, and figures that are consistent with each other."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_line_contract():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "3",
+                        "--no-e2e", "--placement-trials", "2"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 40 and d["warmup"] == 3
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "u8" and d["data"] == "synthetic" and "workload" in d["config"]
+    # value = frames of one step / time of one step
+    frames = d["config"]["frames_per_step_per_gpu"]
+    assert abs(d["value"] - frames / (d["ms_per_step"] / 1e3)) / d["value"] < 0.01
+    rf = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    # achieved = algorithmic bytes per launch / the dominant kernel's measured duration
+    k_ms = d["kernel_ms"]["k_stream"]
+    assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (k_ms / 1e3) / 1e9) / rf["achieved"] < 0.01
+    assert k_ms <= d["ms_per_step"] * 1.02
+    assert 0.3 < rf["frac"] < 1.0
+    if rf["traffic"] is not None:   # PMC bytes can only exceed the algorithmic ones
+        assert rf["traffic"] >= 0.98 * rf["algorithmic_bytes_per_launch"]
+    cb = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cb, k
+    assert cb["kind"] in ("reference", "port") and cb["cores"] == 1 and cb["value"] > 0
+    assert d["inverse"]["roundtrip_bit_exact"] is True

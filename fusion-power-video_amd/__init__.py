@@ -65,6 +65,8 @@ def _declare_hip(lib):
                                                c.POINTER(c.c_double)]
     lib.fpvhip_time_copy_device.restype = c.c_double
     lib.fpvhip_time_copy_device.argtypes = [vp, vp, c.c_size_t, vp, i32]
+    lib.fpvhip_time_copy_shape.restype = c.c_double
+    lib.fpvhip_time_copy_shape.argtypes = [vp, vp, c.c_size_t, vp, i32, i32]
     lib.fpvhip_time_inverse_device.restype = c.c_double
     lib.fpvhip_time_inverse_device.argtypes = [vp, vp, vp, vp, u32, vp, vp, i32]
     if hasattr(lib, "fpvhip_inverse_kernel_name"):   # absent from older diagnostic builds (tools/ab_*.py)
@@ -114,13 +116,15 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
-def copy_bandwidth_GBps(nbytes=1 << 30, iters=10, device=0):
-    """Measured device-copy rate (read + write bytes per second) on this GPU."""
+def copy_bandwidth_GBps(nbytes=1 << 30, iters=10, device=0, shape=1):
+    """Measured device-copy rate (read + write bytes per second) on this GPU.  shape 1: one
+    16-byte element per thread, dispatch-ordered (MI355X_MICROARCH.md's float4 copy); 0: round
+    2's chunked persistent copy."""
     lib = hip_lib()
     src = torch.empty(nbytes, dtype=torch.uint8, device=f"cuda:{device}").random_(0, 255)
     dst = torch.empty_like(src)
-    ms = lib.fpvhip_time_copy_device(_ptr(dst), _ptr(src), nbytes,
-                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), iters)
+    ms = lib.fpvhip_time_copy_shape(_ptr(dst), _ptr(src), nbytes,
+                                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), iters, shape)
     if ms <= 0:
         raise FpvError("copy timing failed")
     return 2.0 * nbytes * iters / (ms / 1e3) / 1e9

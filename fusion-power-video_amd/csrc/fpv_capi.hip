@@ -687,7 +687,7 @@ int fpvhip_warmup(int device) {
   HIPOK(nullptr, hipFree(nullptr));  // creates the primary context
   void* p = nullptr;
   HIPOK(nullptr, hipMalloc(&p, 4096));
-  HIPOK(nullptr, fpvhip::launch_copy(p, p, 0, nullptr));  // loads the code object
+  HIPOK(nullptr, fpvhip::launch_copy(p, p, 0, nullptr, 0));  // loads the code object
   HIPOK(nullptr, hipDeviceSynchronize());
   HIPOK(nullptr, hipFree(p));
   // streams are slow to create (the first one of a process tens of ms, later ones 3-10 ms):
@@ -732,20 +732,25 @@ int fpvhip_inverse_pass_stats(fpvhip_ctx* c, uint32_t* out, int reset) {
   return 0;
 }
 
-double fpvhip_time_copy_device(void* d_dst, const void* d_src, size_t bytes, void* stream,
-                               int iters) {
+double fpvhip_time_copy_shape(void* d_dst, const void* d_src, size_t bytes, void* stream,
+                              int iters, int shape) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipEvent_t a, b;
   if (iters <= 0 || hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1.0;
-  fpvhip::launch_copy(d_src, d_dst, bytes, st);  // warm
+  fpvhip::launch_copy(d_src, d_dst, bytes, st, shape);  // warm
   hipEventRecord(a, st);
-  for (int i = 0; i < iters; i++) fpvhip::launch_copy(d_src, d_dst, bytes, st);
+  for (int i = 0; i < iters; i++) fpvhip::launch_copy(d_src, d_dst, bytes, st, shape);
   hipEventRecord(b, st);
   float ms = -1.f;
   if (hipEventSynchronize(b) == hipSuccess) hipEventElapsedTime(&ms, a, b);
   hipEventDestroy(a);
   hipEventDestroy(b);
   return ms;
+}
+
+double fpvhip_time_copy_device(void* d_dst, const void* d_src, size_t bytes, void* stream,
+                               int iters) {
+  return fpvhip_time_copy_shape(d_dst, d_src, bytes, stream, iters, 1);
 }
 
 double fpvhip_time_inverse_device(fpvhip_ctx* c, const void* d_high,

@@ -28,6 +28,8 @@ struct Geom {
   uint32_t stream_waves_per_cu; // streaming kernel: persistent waves per CU
   uint32_t wg_waves;            // streaming kernel: waves (= consecutive frames) per workgroup
   uint32_t fast;                // streaming kernel: the FAST variant applies (xs % 64 == 0, full steps)
+  // tile pass (fpv_tile.inc): 0 = the geometry takes the streaming kernels instead
+  uint32_t tile_ok, tile_groups, tile_threads, tile_tiles, tile_lds;
   uint32_t nd, ncg;             // sample counts of the two heuristics
   uint32_t ring;                // inverse kernel: LDS ring size (power of two)
   uint32_t inv_ring;            // fast inverse kernel: ring size in pixels (power of two)
@@ -54,7 +56,11 @@ struct FwdWorkspace {
   uint32_t* list_b;      // frames to redo under their true flags
   uint8_t* pvb;          // [nframes][strips] raw first / last preview row of every strip
   uint16_t* partials;    // [nframes][strips][3][256] per-strip histograms of the fused pass
-  uint8_t* spec;         // speculated flags for the next batch
+  uint8_t* spec;         // speculated flags for the next batch (majority of the last one)
+  uint8_t* trec;         // tile pass: [nframes][tiles] per-tile records (partial heuristic histograms, low-byte word)
+  uint8_t* pvraw;        // tile pass: [nframes][npv] raw preview
+  uint32_t* spec_pos;    // tile pass: [nframes] per-position prediction state
+  uint32_t nframes;      // capacity
   size_t zero_bytes;     // leading bytes cleared once at creation (counters, anylow, frame_done, bdone)
   uint32_t seq;          // batches launched so far (selects the counter block); host side
 };
@@ -66,8 +72,9 @@ hipError_t init_fwd_workspace(const FwdWorkspace& ws, hipStream_t s);
 // Per-device one-time set-up of the kernels (function attributes); idempotent, thread-safe.
 void prepare_kernels();
 
-// Plain device copy (bench: measured HBM ceiling).
-hipError_t launch_copy(const void* src, void* dst, size_t bytes, hipStream_t s);
+// Plain device copy (bench: measured HBM ceiling).  shape 1: one 16-byte element per thread,
+// dispatch-ordered (the fastest shape found); 0: round 2's chunked persistent copy.
+hipError_t launch_copy(const void* src, void* dst, size_t bytes, hipStream_t s, int shape = 1);
 
 // Raw split of one frame into byte planes (delta frame set-up, cc:370-451).
 hipError_t launch_split(const Geom& g, const uint16_t* d_img, uint8_t* d_high,

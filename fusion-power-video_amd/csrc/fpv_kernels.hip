@@ -100,10 +100,16 @@ __device__ __forceinline__ uint32_t byte_of(uint32_t v, int k) {
   return (v >> (8 * k)) & 0xffu;
 }
 
-// Streaming copy, 16 B per lane, non-temporal, one contiguous 256 KiB chunk per
-// workgroup and turn: the fastest of the copy shapes tried on MI355X
-// (tools/exp/bw2.hip: 5.3-5.5 TB/s read+write, grid-stride copies reach 4.3-5.0).
-// It is the measured HBM ceiling the predictor kernels are compared with (bench only).
+// Device copies the predictor kernels are compared with (bench only): the measured HBM ceiling.
+// k_copy_simple: one 16-byte element per thread, non-temporal, a workgroup per 4 KiB, nothing
+// looping -- MI355X_MICROARCH.md's "float4 copy" (6.29 TB/s there; 6.5-6.6 TB/s on this pool,
+// tools/exp/bw3.hip).  k_copy: round 2's reference, one contiguous 256 KiB chunk per workgroup and
+// turn (5.5-5.9 TB/s): persistent workgroups that each stream their own region make poorer use
+// of DRAM than workgroups dispatched in memory order -- the observation the tile pass is built on.
+__global__ __launch_bounds__(kThreads) void k_copy_simple(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_t n16) {
+  const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i < n16) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
 constexpr size_t kCopyChunk16 = (256u << 10) / 16;
 __global__ __launch_bounds__(kThreads) void k_copy(const u32x4* __restrict__ src,
                                                   u32x4* __restrict__ dst, size_t n16) {
@@ -1117,6 +1123,14 @@ __device__ __forceinline__ uint64_t entropy_bins(uint32_t v, uint32_t* scratch) 
   return (uint64_t)1024 * s / sum;
 }
 
+// Workgroup barrier behind an LDS-only wait: vector-memory operations of the waves stay in
+// flight across it (__syncthreads() would drain them).
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+#include "fpv_tile.inc"
+
 // ---- exact redo of mis-speculated frames (list driven) ----
 
 constexpr int kListGrid = 256;  // workgroups of k_redo_decide
@@ -1887,9 +1901,6 @@ __global__ __launch_bounds__(64) void k_inverse_spec(
 // LDS-only wait, so the i/o waves' loads stay in flight across it; an i/o wave
 // waits for its own loads (vmcnt) only when it is active again, two iterations
 // after issuing them.
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
 
 // 64 lanes x 4 bytes from per-lane global addresses into LDS at dst + 4 * lane.
 __device__ __forceinline__ void dma4(const uint8_t* src, uint8_t* dst_wave_uniform) {
@@ -2314,6 +2325,33 @@ bool make_geom(uint32_t xs, uint32_t ys, int shift, int big_endian, Geom* g,
       }
     }
   }
+  // Tile pass (fpv_tile.inc): a workgroup per 4 * G rows, a thread per 16-pixel column segment of
+  // a 4-row group (the row above a tile is recomputed: 1 / (4 G) more loads).  Widths that are
+  // not multiples of 64 or beyond 16 K pixels keep the streaming kernels.
+  {
+    const uint32_t ncs = xs / 16;
+    // Workgroup sizes that fill the CU's wave slots evenly at this kernel's register budget (16
+    // waves per CU): 512 threads where that gives at least 4 groups, else 1024 (measured at
+    // 1280x800: G = 6 / 512 threads 0.72 ms, G = 4 / 320 threads 0.88, G = 8 / 640 threads 1.0).
+    uint32_t G = ncs ? 512u / ncs : 0;
+    if (G < 4 && ncs) G = 1024u / ncs;
+    if (const char* e = getenv("FPV_TILE_GROUPS")) G = std::max(1u, (uint32_t)atoi(e));
+    if (ncs && G * ncs > 1024) G = 1024 / ncs;
+    G = std::min(G, ys / 4);
+    const char* fwd = getenv("FPV_FORWARD");  // "stream": round 2's kernels (A/B runs, tests)
+    g->tile_ok = 0;
+    if ((xs & 63) == 0 && ncs <= 1024 && G >= 1 && !(fwd && fwd[0] == 's')) {
+      const uint32_t T = std::max(256u, round_up(G * ncs, 64));  // the finishing path wants 256 threads
+      const uint32_t tiles = (ys + 4 * G - 1) / (4 * G);
+      if (T <= 1024 && tiles <= 65535) {
+        g->tile_ok = 1;
+        g->tile_groups = G;
+        g->tile_threads = T;
+        g->tile_tiles = tiles;
+        g->tile_lds = tile_lds_bytes(G, ncs);
+      }
+    }
+  }
   g->nd = (g->npix + 14) / 15;
   g->ncg = g->npix > xs + 1 ? (g->npix - xs - 1 + 30) / 31 : 0;
   uint32_t ring = 1;
@@ -2352,6 +2390,11 @@ bool make_geom_decoder(uint32_t xs, uint32_t ys, Geom* g, const char** why) {
 size_t fwd_workspace_bytes(const Geom& g, uint32_t max_frames) {
   size_t b = 512 + 2 * (size_t)round_up(max_frames * 4, 256);    // counter blocks, anylow, frame_done
   b += round_up((size_t)max_frames * g.redo_strips * 4, 256);    // boundary words
+  if (g.tile_ok) {
+    b += round_up((size_t)max_frames * g.tile_tiles * kTileRecBytes, 256);  // tile records
+    b += round_up((size_t)max_frames * g.npv, 256);              // raw previews
+    b += round_up(max_frames * 4, 256);                          // per-position prediction
+  }
   b += round_up(max_frames, 256);                                // decision
   b += 2 * (size_t)round_up(max_frames * 4, 256);                // list A, list B
   b += round_up((size_t)max_frames * g.redo_strips * g.pvb_stride, 256);  // boundary preview rows (redo_strips >= strips)
@@ -2370,7 +2413,17 @@ void carve_fwd_workspace(const Geom& g, uint32_t max_frames, void* base,
   p += round_up(max_frames * 4, 256);
   ws->bdone = reinterpret_cast<uint32_t*>(p);
   p += round_up((size_t)max_frames * g.redo_strips * 4, 256);
+  ws->trec = nullptr; ws->pvraw = nullptr; ws->spec_pos = nullptr;
+  ws->nframes = max_frames;
   ws->zero_bytes = (size_t)(p - static_cast<uint8_t*>(base));
+  if (g.tile_ok) {
+    ws->trec = p;
+    p += round_up((size_t)max_frames * g.tile_tiles * kTileRecBytes, 256);
+    ws->pvraw = p;
+    p += round_up((size_t)max_frames * g.npv, 256);
+    ws->spec_pos = reinterpret_cast<uint32_t*>(p);
+    p += round_up(max_frames * 4, 256);
+  }
   ws->decision = p;
   p += round_up(max_frames, 256);
   ws->list_a = reinterpret_cast<uint32_t*>(p);
@@ -2388,12 +2441,20 @@ void carve_fwd_workspace(const Geom& g, uint32_t max_frames, void* base,
 hipError_t init_fwd_workspace(const FwdWorkspace& ws, hipStream_t s) {
   hipError_t e = hipMemsetAsync(ws.ctr, 0, ws.zero_bytes, s);
   if (e != hipSuccess) return e;
+  if (ws.spec_pos) {  // no position has a history yet: the majority guess applies
+    e = hipMemsetAsync(ws.spec_pos, 3, (size_t)ws.nframes * 4, s);  // dwords 0x03030303: decision 3, "repeated" clear
+    if (e != hipSuccess) return e;
+  }
   return hipMemsetAsync(ws.spec, 3, 4, s);  // first guess: delta + CG
 }
 
-hipError_t launch_copy(const void* src, void* dst, size_t bytes, hipStream_t s) {
-  k_copy<<<256 * 32, kThreads, 0, s>>>(static_cast<const u32x4*>(src), static_cast<u32x4*>(dst),
-                                       bytes / 16);
+hipError_t launch_copy(const void* src, void* dst, size_t bytes, hipStream_t s, int shape) {
+  const size_t n16 = bytes / 16;
+  if (shape == 1) {
+    if (n16) k_copy_simple<<<(unsigned)((n16 + kThreads - 1) / kThreads), kThreads, 0, s>>>(static_cast<const u32x4*>(src), static_cast<u32x4*>(dst), n16);
+  } else {
+    k_copy<<<256 * 32, kThreads, 0, s>>>(static_cast<const u32x4*>(src), static_cast<u32x4*>(dst), n16);
+  }
   return hipGetLastError();
 }
 
@@ -2473,6 +2534,37 @@ static hipError_t predict_impl(const Geom& g, const uint16_t* d_frames,
                                uint8_t* d_preview, uint8_t* d_flags,
                                hipStream_t s, hipEvent_t* ev) {
   const int with_delta = d_dhigh != nullptr;
+  if (g.tile_ok && ws.trec) {  // dispatch-ordered tiles (fpv_tile.inc)
+    TileLaunch L;
+    TileArgs& a = L.g;
+    a.xs = g.xs; a.ys = g.ys; a.npix = g.npix; a.pw = g.pw; a.npv = g.npv;
+    a.ncs = g.xs / 16; a.groups = g.tile_groups; a.tiles = g.tile_tiles; a.nitems = a.groups * a.ncs;
+    a.shift = (uint32_t)g.shift; a.nframes = nframes; a.with_delta = (uint32_t)with_delta;
+    a.in_pitch = a.out_pitch = g.npix;
+    a.xs15 = g.xs % 15u; a.xs31 = g.xs % 31u; a.c31 = (g.xs + 1u) % 31u; a.ncg = g.ncg;
+    TilePtrs& P = L.P;
+    P.frames = d_frames; P.dhigh = d_dhigh; P.dlow = d_dlow;
+    P.high = d_high; P.low = d_low; P.preview = d_preview; P.flags = d_flags;
+    P.trec = ws.trec; P.pvraw = ws.pvraw;
+    P.ctr = ws.ctr + (ws.seq & 1u) * 64;
+    P.ctr_next = ws.ctr + ((ws.seq + 1) & 1u) * 64;
+    ws.seq++;
+    P.decision = ws.decision; P.list_a = ws.list_a; P.list_b = ws.list_b; P.spec = reinterpret_cast<uint32_t*>(ws.spec); P.spec_pos = ws.spec_pos;
+    const bool lowp = g.shift != 8;
+    const uint32_t T = g.tile_threads, lds = g.tile_lds;
+    if (ev) hipEventRecord(ev[0], s);
+    if (lowp) k_tile<SWAP, true><<<nframes * g.tile_tiles, T, lds, s>>>(L);
+    else k_tile<SWAP, false><<<nframes * g.tile_tiles, T, lds, s>>>(L);
+    if (ev) hipEventRecord(ev[1], s);
+    k_tile_decide<SWAP><<<nframes, kDecideThreads, 0, s>>>(L);
+    if (ev) hipEventRecord(ev[2], s);
+    const uint32_t rgrid = std::min<uint32_t>(nframes * g.tile_tiles, device_cus() * std::max(1u, 2048u / T));
+    if (lowp) k_redo_tiles<SWAP, true><<<rgrid, T, lds, s>>>(L);
+    else k_redo_tiles<SWAP, false><<<rgrid, T, lds, s>>>(L);
+    if (ev) hipEventRecord(ev[3], s);
+    if (ev) hipEventRecord(ev[4], s);
+    return hipGetLastError();
+  }
   StreamArgs a;
   a.xs = g.xs; a.ys = g.ys; a.npix = g.npix; a.pw = g.pw; a.npv = g.npv;
   a.in_pitch = a.out_pitch = g.npix;

@@ -229,6 +229,11 @@ const char *fpvhip_inverse_kernel_name(fpvhip_ctx *ctx, uint32_t nframes);
  * `stream`; returns elapsed ms.  The measured HBM ceiling kernels are compared with. */
 double fpvhip_time_copy_device(void *d_dst, const void *d_src, size_t bytes,
                                void *stream, int iters);
+/* The same for a named copy shape: 1 = one 16-byte element per thread, workgroups dispatched
+ * in memory order (what fpvhip_time_copy_device measures: the fastest shape found on
+ * MI355X), 0 = persistent workgroups copying 256 KiB chunks (round 2's reference). */
+double fpvhip_time_copy_shape(void *d_dst, const void *d_src, size_t bytes,
+                              void *stream, int iters, int shape);
 double fpvhip_time_inverse_device(fpvhip_ctx *ctx, const void *d_high,
                                   const void *d_low, const void *d_flags,
                                   uint32_t nframes, void *d_frames,

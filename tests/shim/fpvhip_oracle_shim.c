@@ -48,6 +48,7 @@ const char *fpvhip_inverse_kernel_name(fpvhip_ctx *c, uint32_t n) { (void)c; (vo
 int fpvhip_debug_counters(fpvhip_ctx *c, uint32_t *out, uint32_t n) { (void)c; (void)out; (void)n; return -1; }
 double fpvhip_slot_elapsed_ms(fpvhip_ctx *c, uint32_t slot) { (void)c; (void)slot; return 0.0; }
 double fpvhip_time_copy_device(void *d, const void *s, size_t b, void *st, int it) { (void)d; (void)s; (void)b; (void)st; (void)it; return -1.0; }
+double fpvhip_time_copy_shape(void *d, const void *s, size_t b, void *st, int it, int sh) { (void)d; (void)s; (void)b; (void)st; (void)it; (void)sh; return -1.0; }
 
 static fpvhip_ctx *mk(uint32_t xs, uint32_t ys, int shift, int be, uint32_t batch,
                       uint32_t slots, int fwd) {

@@ -15,10 +15,11 @@ def _check(fpv, oracle, frames, shift, expect_flags=None):
     p = fpv.Predictor(xs, ys, shift, False, max_batch=n)
     p.set_delta_raw(frames[0])
     d = torch.from_numpy(frames.reshape(n, -1).view(np.int16)).cuda().view(torch.uint16)
-    for rep in range(2):   # the second batch starts from the speculation the first one left behind
+    ctrs = []
+    for rep in range(3):   # later batches start from the predictions the earlier ones left behind
         high, low, pv, flags = p.predict(d)
         torch.cuda.synchronize()
-        ctr = p.debug_counters()
+        ctrs.append(p.debug_counters())
         fl = flags.cpu().numpy()
         for k in range(n):
             eh, el, ep, ef = oracle.predict(frames[k], xs, ys, shift, False, frames[0])
@@ -27,19 +28,21 @@ def _check(fpv, oracle, frames, shift, expect_flags=None):
             assert np.array_equal(low[k].cpu().numpy(), el), (rep, k)
             assert np.array_equal(pv[k].cpu().numpy(), ep), (rep, k)
     p.close()
-    return fl, ctr
+    return fl, ctrs
 
 
 def test_noise_1280x800_mis_speculation(fpv, synth, oracle):
     fr = synth.noise_frames(12, 1280, 800, seed=1)
-    fl, ctr = _check(fpv, oracle, fr, 0)
+    fl, ctrs = _check(fpv, oracle, fr, 0)
     assert len(set(int(f) & 2 for f in fl)) == 2          # both CG decisions occur
-    assert ctr[1] > 0                                       # frames went through the redo pass
+    assert ctrs[0][1] > 0                                   # first batch: frames went through the redo pass
 
 
 def test_alternating_flat_frames_flip_the_delta_decision(fpv, synth, oracle):
     fr = synth.plasma_frames(10, 1280, 800, bits=12, seed=7)
     fr[1::2] = 0x0123                                        # E(hist) == 0: no delta (cc:528-533)
-    fl, ctr = _check(fpv, oracle, fr, 4)
+    fl, ctrs = _check(fpv, oracle, fr, 4)
     assert {int(f) & 1 for f in fl} == {0, 1}
-    assert ctr[0] > 0                                       # list A: delta decision mis-speculated
+    assert ctrs[0][0] > 0                                   # list A: delta decision mis-speculated
+    # the prediction is per batch position: once a position's decision has repeated it is predicted
+    assert ctrs[2][0] == 0 and ctrs[2][1] == 0

@@ -87,13 +87,17 @@ def test_partial_batches_reuse_workspace(fpv, synth, oracle):
     p.close()
 
 
-@pytest.mark.parametrize("env", [{"FPV_STRIP_ROWS": "4"}, {"FPV_STRIP_ROWS": "80", "FPV_STRIP_MAJOR": "0"}, {"FPV_STRIP_ROWS": "12", "FPV_WAVES_PER_CU": "2"},
+@pytest.mark.parametrize("env", [{"FPV_FORWARD": "stream", "FPV_STRIP_ROWS": "4"}, {"FPV_FORWARD": "stream", "FPV_STRIP_ROWS": "80", "FPV_STRIP_MAJOR": "0"},
+                                 {"FPV_FORWARD": "stream", "FPV_STRIP_ROWS": "12", "FPV_WAVES_PER_CU": "2"}, {"FPV_FORWARD": "stream"},
+                                 {"FPV_TILE_GROUPS": "1"}, {"FPV_TILE_GROUPS": "7"}, {"FPV_TILE_GROUPS": "50"},
                                  {"FPV_INVERSE_SLOW": "1"}, {"FPV_INVERSE": "fast"}, {"FPV_INVERSE": "spec"},
                                  {"FPV_INVERSE": "trio"}])
 def test_alternate_kernel_paths(fpv, synth, oracle, env):
-    """Odd strip sizes (partial last steps, non-FAST streaming variant), the
-    frame-major task order and every inverse kernel (byte-granular, serial chain,
-    one-wave and three-wave speculative) must give the same bits as the defaults."""
+    """The streaming forward kernels (round 2; still the path of widths that are not multiples
+    of 64) with odd strip sizes and the frame-major task order, the tile pass with other tile
+    heights (one group per tile, a last tile that is partly outside the frame, the whole frame
+    as one tile) and every inverse kernel (byte-granular, serial chain, one-wave and three-wave
+    speculative) must give the same bits as the defaults."""
     import os
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)

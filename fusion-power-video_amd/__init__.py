@@ -72,6 +72,9 @@ def _declare_hip(lib):
     if hasattr(lib, "fpvhip_inverse_kernel_name"):   # absent from older diagnostic builds (tools/ab_*.py)
         lib.fpvhip_inverse_kernel_name.restype = c.c_char_p
         lib.fpvhip_inverse_kernel_name.argtypes = [vp, u32]
+    if hasattr(lib, "fpvhip_forward_kernel_names"):
+        lib.fpvhip_forward_kernel_names.restype = c.c_char_p
+        lib.fpvhip_forward_kernel_names.argtypes = [vp]
     lib.fpvhip_debug_counters.restype = i32
     lib.fpvhip_debug_counters.argtypes = [vp, c.POINTER(c.c_uint32), u32]
     lib.fpvhip_inverse_pass_stats.restype = i32
@@ -86,7 +89,7 @@ def hip_lib():
     """The C-ABI library (include/fpv_hip.h).  Raises when it is not built."""
     global _hip
     if _hip is None:
-        path = os.environ.get("FPV_HIP_LIB") or os.path.join(LIBDIR, "libfpvhip.so")  # override: diagnostic builds
+        path = os.path.join(LIBDIR, "libfpvhip.so")  # diagnostic builds are loaded explicitly (tools/ab_forward.py), never through the environment
         if not os.path.exists(path):
             raise FpvError(f"{path} is missing: run `make product` (no CPU fallback exists)")
         _hip = ctypes.CDLL(path)
@@ -229,6 +232,12 @@ class Predictor:
         buf = (ctypes.c_uint32 * n)()
         self._check(self.lib.fpvhip_debug_counters(self.ctx, buf, n), "debug_counters")
         return [int(v) for v in buf]
+
+    def forward_kernel_names(self):
+        """The three launches of one forward batch, in the order of time_predict(per_kernel=True)."""
+        if not hasattr(self.lib, "fpvhip_forward_kernel_names"):
+            return ["k_stream", "k_redo_decide", "k_redo_stream"]
+        return self.lib.fpvhip_forward_kernel_names(self.ctx).decode().split(",")
 
     def inverse_kernel_name(self, nframes):
         """Which inverse kernel launch_inverse picks for this batch size (FPV_INVERSE unset)."""

@@ -3,7 +3,9 @@
 the REAL reference (oracle/_ref/encode = the upstream encode.cc + library compiled here by
 oracle/Makefile) on the cycled synthetic frames.  Only data (hashes, sizes) is stored.
 
-  config 1 at its stated size: 1000 frames 1280x800 12-bit plasma, 64 distinct frames cycled."""
+  config 1 at its stated size: 1000 frames 1280x800 12-bit plasma, 64 distinct frames cycled.
+  config 3 at its stated size: 1000 frames 4096x4096 16-bit plasma, 8 distinct frames cycled
+  (`python make_golden_long.py config3`: about a minute of reference CPU time on 8 cores)."""
 import hashlib, importlib, json, os, subprocess, sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -36,6 +38,16 @@ def ref_stream_sha(frames, total, xs, ys, shift, threads=8):
 
 def main():
     man = json.load(open(os.path.join(HERE, "manifest.json")))
+    if "config3" in sys.argv[1:]:
+        fr = synth.plasma_frames(8, 4096, 4096, bits=16, seed=11)
+        sha, size = ref_stream_sha(fr, 1000, 4096, 4096, 0)
+        man["workloads"]["plasma16_4096x4096x1000_cycled8_seed11"] = {
+            "xs": 4096, "ys": 4096, "shift": 0, "big_endian": False, "frames": 1000, "distinct": 8,
+            "note": "frame i = synth.plasma_frames(8, 4096, 4096, bits=16, seed=11)[i % 8]; delta frame = frame 0 (encode.cc:87-90)",
+            "fpv_sha256": sha, "fpv_size": size, "generator": "tests/golden/make_golden_long.py config3"}
+        json.dump(man, open(os.path.join(HERE, "manifest.json"), "w"), indent=1)
+        print(sha, size)
+        return
     fr = synth.plasma_frames(64, 1280, 800, bits=12, seed=7)
     sha, size = ref_stream_sha(fr, 1000, 1280, 800, 4)
     man["workloads"]["plasma12_1280x800x1000_cycled64_seed7"] = {

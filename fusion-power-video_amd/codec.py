@@ -28,6 +28,8 @@ def declare(lib):
     lib.fpvc_encoder_finish.argtypes = [c.c_void_p, WRITE_FN, c.c_void_p]
     lib.fpvc_encoder_free.restype = None
     lib.fpvc_encoder_free.argtypes = [c.c_void_p]
+    lib.fpvc_encoder_last_error.restype = c.c_char_p
+    lib.fpvc_encoder_last_error.argtypes = [c.c_void_p]
     lib.fpvc_encode_stream.restype = c.c_size_t
     lib.fpvc_encode_stream.argtypes = [_u16p, c.c_size_t, _u16p, c.c_size_t, c.c_size_t, c.c_int,
                                        c.c_int, c.c_size_t, _u8p, c.c_size_t]
@@ -85,6 +87,7 @@ class Codec:
             self.lib.fpvc_encoder_compress_frame(enc, np.ascontiguousarray(frames[i]), cb, c.c_void_p(i + 1))
         self.lib.fpvc_encoder_finish(enc, cb, c.c_void_p(2000000))
         self.lib.fpvc_encoder_finish(enc, cb, c.c_void_p(3000000))   # second call: no-op
+        self.last_error = self.lib.fpvc_encoder_last_error(enc).decode()
         self.lib.fpvc_encoder_free(enc)
         return mq, got
 

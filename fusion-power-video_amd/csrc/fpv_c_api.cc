@@ -48,6 +48,7 @@ void fpvc_encoder_free(void* enc) { delete static_cast<fpvc::Encoder*>(enc); }
 size_t fpvc_encoder_stats(const void* enc, double* out, size_t n) {
   return static_cast<const fpvc::Encoder*>(enc)->LastStats(out, n);
 }
+const char* fpvc_encoder_last_error(const void* enc) { return static_cast<const fpvc::Encoder*>(enc)->LastError(); }
 
 // Encoder construction -> Finish over `total` frames that cycle through `distinct`
 // resident ones, timed like the upstream benchmark times it (benchmark.cc:153-180); the

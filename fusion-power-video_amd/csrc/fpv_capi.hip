@@ -187,7 +187,9 @@ double now_ms() {
 }
 const bool g_timing = getenv("FPV_TIMING") != nullptr;
 
-int alloc_slot(fpvhip_ctx* c, Slot* s) {
+void free_slot(Slot* s);
+
+int alloc_slot_impl(fpvhip_ctx* c, Slot* s) {
   const double t_begin = now_ms();
   const size_t B = c->max_batch, np = c->g.npix, nv = c->g.npv;
   auto up16 = [](size_t v) { return (v + 255) & ~(size_t)255; };
@@ -223,11 +225,25 @@ int alloc_slot(fpvhip_ctx* c, Slot* s) {
   return 0;
 }
 
+// Gives back everything a slot holds and leaves it empty (a later check_slot allocates it
+// again; a slot whose allocation failed half-way must not keep what it got: the retry would
+// overwrite, i.e. leak, it).
 void free_slot(Slot* s) {
   pinned_free(&s->host);
-  hipFree(s->dev); hipFree(s->d_ws);
-  for (hipEvent_t e : {s->done, s->begin, s->up_done, s->k_done})
-    if (e) hipEventDestroy(e);
+  if (s->dev) hipFree(s->dev);
+  if (s->d_ws) hipFree(s->d_ws);
+  s->dev = nullptr;
+  s->d_ws = nullptr;
+  for (hipEvent_t* e : {&s->done, &s->begin, &s->up_done, &s->k_done})
+    if (*e) { hipEventDestroy(*e); *e = nullptr; }
+  s->h_pix = nullptr; s->h_high = s->h_low = s->h_pv = s->h_flags = nullptr; s->h_delta = nullptr;
+  s->d_pix = nullptr; s->d_high = s->d_low = s->d_pv = s->d_flags = nullptr;
+}
+
+int alloc_slot(fpvhip_ctx* c, Slot* s) {
+  const int rc = alloc_slot_impl(c, s);
+  if (rc != 0) free_slot(s);
+  return rc;
 }
 
 // Only slot 0 is allocated by create; the others when they are first touched,
@@ -435,7 +451,9 @@ int fpvhip_split_frame(fpvhip_ctx* c, const uint16_t* img, uint8_t* high, uint8_
   const size_t np = c->g.npix;
   HIPOK(c, hipSetDevice(c->device));
   uint32_t any = 0;
-  {
+  // `any` lives on this stack frame and the copy into it is asynchronous: whatever fails, the
+  // stream is drained before the frame is left.
+  auto queue = [&]() -> int {
     std::lock_guard<std::mutex> l(c->xfer_m);
     HIPOK(c, hipMemcpyAsync(s.d_pix, img, np * 2, hipMemcpyHostToDevice, c->comp));
     HIPOK(c, hipMemsetAsync(s.ws.anylow, 0, 4, c->comp));
@@ -445,8 +463,12 @@ int fpvhip_split_frame(fpvhip_ctx* c, const uint16_t* img, uint8_t* high, uint8_
       HIPOK(c, hipMemcpyAsync(low, s.d_low, np, hipMemcpyDeviceToHost, c->comp));
     HIPOK(c, hipMemcpyAsync(&any, s.ws.anylow, 4, hipMemcpyDeviceToHost, c->comp));
     HIPOK(c, hipMemsetAsync(s.ws.anylow, 0, 4, c->comp));  // the predictor expects its accumulators clean
-  }
-  HIPOK(c, hipStreamSynchronize(c->comp));
+    return 0;
+  };
+  const int rc = queue();
+  const hipError_t es = hipStreamSynchronize(c->comp);
+  if (rc != 0) return rc;
+  if (es != hipSuccess) return fail(c, "hipStreamSynchronize failed: %s", hipGetErrorString(es));
   *no_low = any == 0;
   return 0;
 }

@@ -41,6 +41,7 @@ fpvhip_ctx* AcquireEncoderCtx(int device, uint32_t xs, uint32_t ys, int shift,
       }
     }
   }
+  WarmUpWait();
   fpvhip_ctx* c = fpvhip_create(device, xs, ys, shift, big_endian ? 1 : 0, batch, slots);
   if (!c) return nullptr;
   std::lock_guard<std::mutex> l(g_pool_m);
@@ -50,9 +51,10 @@ fpvhip_ctx* AcquireEncoderCtx(int device, uint32_t xs, uint32_t ys, int shift,
 
 // Idle contexts stay cached for the next session of the same geometry, bounded by count and
 // by the pinned staging memory they hold (FPV_POOL_MB, default 1024): beyond the byte bound
-// idle contexts first give back all slots but one (fpvhip_trim), then the oldest are
-// destroyed.  Whatever a reused context remembers (delta planes, speculation byte) is
-// overwritten by Init / harmless.
+// the idle contexts first give back all slots but one (fpvhip_trim: stream syncs and
+// unregistration, so it runs OUTSIDE the pool lock on contexts marked busy meanwhile), then the
+// oldest are destroyed until the total is under the bound.  Whatever a reused context remembers
+// (delta planes, prediction state) is overwritten by Init / harmless.
 void ReleaseEncoderCtx(fpvhip_ctx* ctx) {
   std::vector<fpvhip_ctx*> drop, trim;
   const size_t cap = EnvSize("FPV_POOL_MB", 1024) << 20;
@@ -63,11 +65,9 @@ void ReleaseEncoderCtx(fpvhip_ctx* ctx) {
       if (e.ctx == ctx) e.in_use = false;
       if (!e.in_use) { idle++; bytes += fpvhip_staging_bytes(e.ctx); }
     }
-    if (bytes > cap)
-      for (auto& e : g_pool)
-        if (!e.in_use) trim.push_back(e.ctx);
-    for (size_t i = 0; i < g_pool.size() && idle > kMaxIdle;) {
+    for (size_t i = 0; i < g_pool.size() && idle > kMaxIdle;) {  // count bound: the oldest go
       if (!g_pool[i].in_use && g_pool[i].ctx != ctx) {
+        bytes -= fpvhip_staging_bytes(g_pool[i].ctx);
         drop.push_back(g_pool[i].ctx);
         g_pool.erase(g_pool.begin() + i);
         idle--;
@@ -75,11 +75,30 @@ void ReleaseEncoderCtx(fpvhip_ctx* ctx) {
         i++;
       }
     }
-    // trimming happens under the lock: an idle context must not be acquired meanwhile
-    for (fpvhip_ctx* c : trim) {
-      bool gone = false;
-      for (fpvhip_ctx* d : drop) gone |= d == c;
-      if (!gone) fpvhip_trim(c);
+    if (bytes > cap)
+      for (auto& e : g_pool)
+        if (!e.in_use) {
+          e.in_use = true;  // nobody may acquire it while it is being trimmed
+          trim.push_back(e.ctx);
+        }
+  }
+  for (fpvhip_ctx* c : trim) fpvhip_trim(c);
+  if (!trim.empty()) {
+    std::lock_guard<std::mutex> l(g_pool_m);
+    size_t bytes = 0;
+    for (auto& e : g_pool) {
+      for (fpvhip_ctx* c : trim)
+        if (e.ctx == c) e.in_use = false;
+      if (!e.in_use) bytes += fpvhip_staging_bytes(e.ctx);
+    }
+    for (size_t i = 0; i < g_pool.size() && bytes > cap;) {  // still above the bound: the oldest idle contexts go
+      if (!g_pool[i].in_use) {
+        bytes -= fpvhip_staging_bytes(g_pool[i].ctx);
+        drop.push_back(g_pool[i].ctx);
+        g_pool.erase(g_pool.begin() + i);
+      } else {
+        i++;
+      }
     }
   }
   for (fpvhip_ctx* c : drop) fpvhip_destroy(c);
@@ -95,6 +114,7 @@ fpvhip_ctx* AcquireDecoderCtx(int device, uint32_t xs, uint32_t ys) {
       }
     }
   }
+  WarmUpWait();
   fpvhip_ctx* c = fpvhip_create_decoder(device, xs, ys, 1, 1);
   if (!c) return nullptr;
   std::lock_guard<std::mutex> l(g_pool_m);
@@ -109,6 +129,7 @@ void ReleaseDecoderCtx(fpvhip_ctx* ctx) { ReleaseEncoderCtx(ctx); }
 std::shared_ptr<InverseEngine> InverseEngine::Create(size_t xs, size_t ys, uint32_t batch,
                                                      uint32_t slots, int device) {
   std::shared_ptr<InverseEngine> e(new InverseEngine());
+  WarmUpWait();
   e->ctx_ = fpvhip_create_decoder(device, (uint32_t)xs, (uint32_t)ys, batch, slots);
   if (!e->ctx_) {
     fprintf(stderr, "fpv-mi355x: cannot create GPU decoder context: %s\n", fpvhip_last_error(nullptr));

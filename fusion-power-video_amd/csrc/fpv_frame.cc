@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <future>
 #include <map>
@@ -22,7 +23,11 @@ using namespace internal;
 Frame Frame::EMPTY(0, 0);
 
 namespace {
-int FrameDevice() { return DeviceList()[0]; }
+int FrameDevice() {
+  const std::vector<int> d = DeviceList();
+  if (d.empty()) Fatal("Frame: no usable GPU", fpvhip_last_error(nullptr));
+  return d[0];
+}
 
 struct Fwd {  // leased forward context (batch 1, one slot)
   fpvhip_ctx* ctx;
@@ -80,21 +85,43 @@ std::mutex& SplitLock(const void* frame) {
 // up its own planes.  A lone caller gets a batch of one at once: nothing waits for company.
 class PredictCombiner {
  public:
-  static constexpr uint32_t kMaxBatch = 16, kSlots = 2;
+  // Frames per GPU batch: up to 16, bounded by a byte budget of pinned staging per slot (in +
+  // out = 4 bytes per pixel: 64 MB -> 16 frames up to 1 Mpixel, 4 at 4 Mpixel, 1 at 4096x4096);
+  // FPV_COMBINER_MB overrides.  A combiner nobody has used for a while gives its context back.
+  static constexpr uint32_t kMaxBatchCap = 16, kSlots = 2;
+  static uint32_t BatchFor(size_t npix) {
+    const size_t budget = EnvSize("FPV_COMBINER_MB", 64) << 20;
+    return (uint32_t)std::min<size_t>(kMaxBatchCap, std::max<size_t>(1, budget / std::max<size_t>(1, npix * 4)));
+  }
   typedef std::tuple<int, size_t, size_t, int, bool> Key;  // device, xs, ys, shift, big endian
 
   static std::shared_ptr<PredictCombiner> Get(const Key& key) {
     static std::mutex m;
     static std::map<Key, std::shared_ptr<PredictCombiner>>* all = new std::map<Key, std::shared_ptr<PredictCombiner>>();
     std::lock_guard<std::mutex> l(m);
+    // A combiner nobody holds and nobody has used for a while gives its context back to the
+    // pool of idle contexts, where the FPV_POOL_MB bound applies (it used to stay leased for
+    // the life of the process).
+    const int64_t now = NowMs(), idle_ms = (int64_t)EnvSize("FPV_COMBINER_IDLE_MS", 2000);
+    for (auto d = all->begin(); d != all->end();) {
+      if (d->first != key && d->second.use_count() == 1 && now - d->second->last_used_ms_.load() > idle_ms) d = all->erase(d);
+      else ++d;
+    }
     auto it = all->find(key);
-    if (it != all->end()) return it->second;
+    if (it != all->end()) {
+      it->second->last_used_ms_.store(now);
+      return it->second;
+    }
     if (all->size() >= 4)  // keep the pinned memory bounded: drop a geometry nobody is using
       for (auto d = all->begin(); d != all->end(); ++d)
         if (d->second.use_count() == 1) { all->erase(d); break; }
     std::shared_ptr<PredictCombiner> c(new PredictCombiner(key));
+    c->last_used_ms_.store(now);
     (*all)[key] = c;
     return c;
+  }
+  static int64_t NowMs() {
+    return std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
   }
 
   ~PredictCombiner() { ReleaseEncoderCtx(ctx_); }
@@ -108,7 +135,7 @@ class PredictCombiner {
     std::unique_lock<std::mutex> l(m_);
     Batch* b = nullptr;
     for (;;) {
-      if (open_ && open_->delta == delta_id && open_->joined < kMaxBatch) { b = open_; break; }
+      if (open_ && open_->delta == delta_id && open_->joined < max_batch_) { b = open_; break; }
       if (!open_) {
         const int s = slot_free_[0] ? 0 : slot_free_[1] ? 1 : -1;
         if (s >= 0) {
@@ -173,21 +200,24 @@ class PredictCombiner {
     const uint8_t *high = nullptr, *low = nullptr, *preview = nullptr, *flags = nullptr;
   };
   explicit PredictCombiner(const Key& k)
-      : npix_(std::get<1>(k) * std::get<2>(k)), npv_((std::get<1>(k) / 4) * (std::get<2>(k) / 4)) {
+      : npix_(std::get<1>(k) * std::get<2>(k)), npv_((std::get<1>(k) / 4) * (std::get<2>(k) / 4)),
+        max_batch_(BatchFor(std::get<1>(k) * std::get<2>(k))) {
     ctx_ = AcquireEncoderCtx(std::get<0>(k), (uint32_t)std::get<1>(k), (uint32_t)std::get<2>(k), std::get<3>(k),
-                             std::get<4>(k), kMaxBatch, kSlots);
+                             std::get<4>(k), max_batch_, kSlots);
     if (!ctx_) Fatal("Frame: fpvhip_create", fpvhip_last_error(nullptr));
   }
   std::mutex m_;
   std::condition_variable cv_;
   fpvhip_ctx* ctx_ = nullptr;
   size_t npix_, npv_;
+  uint32_t max_batch_;
+  std::atomic<int64_t> last_used_ms_{0};
   uint64_t ctx_delta_ = 0;  // content id of the delta frame the context holds (0: unknown / none)
   bool slot_free_[kSlots] = {true, true};
   bool inflight_ = false;
   Batch* open_ = nullptr;
 };
-constexpr uint32_t PredictCombiner::kMaxBatch;
+constexpr uint32_t PredictCombiner::kMaxBatchCap;
 }  // namespace
 
 size_t Frame::MaxCompressedPlaneSize(size_t xsize, size_t ysize) {
@@ -226,6 +256,29 @@ void Frame::SplitNow() const {
         f.ctx, "fpvhip_split_frame");
   if (no_low) self->flags_ |= FrameFlags::NO_LOW_BYTES;
   __atomic_store_n(&planes_pending_, 0, __ATOMIC_RELEASE);
+}
+
+// Copying reads the planes, the flags and the pending mark: under the source's split lock, so
+// that a split running on another thread is either wholly seen or not at all.
+void Frame::CopyFrom(const Frame& o) {
+  std::lock_guard<std::mutex> l(SplitLock(&o));
+  preview_ = o.preview_;
+  high_ = o.high_;
+  low_ = o.low_;
+  xsize_ = o.xsize_; ysize_ = o.ysize_; size_ = o.size_;
+  flags_ = o.flags_;
+  state_ = o.state_;
+  timestamp_ = o.timestamp_;
+  pixels_ = o.pixels_;
+  shift_ = o.shift_;
+  big_endian_ = o.big_endian_;
+  content_id_ = o.content_id_;
+  __atomic_store_n(&planes_pending_, __atomic_load_n(&o.planes_pending_, __ATOMIC_ACQUIRE), __ATOMIC_RELEASE);
+}
+Frame::Frame(const Frame& other) { CopyFrom(other); }
+Frame& Frame::operator=(const Frame& other) {
+  if (this != &other) CopyFrom(other);
+  return *this;
 }
 
 void Frame::Touch() {

@@ -46,9 +46,9 @@ bool Failure(const char* file, int line, const char* msg) {
   return false;
 }
 
-// The encoder API is void everywhere (cc:1086-1157): a GPU failure cannot be
-// reported to the caller, and silently producing nothing would corrupt the
-// stream.  Fail loudly.
+// API misuse (Init twice, CompressFrame before Init) and, with FPV_ABORT_ON_ERROR=1, any GPU
+// failure: one message, then abort().  By default a GPU failure in an Encoder is latched
+// instead (Encoder::LastError): the session stops accepting frames and Finish emits no index.
 void Fatal(const char* what, const char* detail) {
   fprintf(stderr, "fpv-mi355x: fatal: %s: %s\n", what, detail ? detail : "");
   fprintf(stderr, "fpv-mi355x: the predictor stage has no CPU fallback; a usable "
@@ -203,8 +203,8 @@ void ParallelFor(size_t n, size_t threads, const std::function<void(size_t)>& fn
 // GPUs used by the encoder: FPV_DEVICES="0,2,3" or every visible device.
 std::vector<int> DeviceList() {
   int n = fpvhip_device_count();
-  if (n <= 0) Fatal("no usable GPU", fpvhip_last_error(nullptr));
   std::vector<int> devs;
+  if (n <= 0) return devs;  // callers report it (no CPU fallback exists)
   if (const char* env = getenv("FPV_DEVICES")) {
     for (const char* p = env; *p;) {
       char* end;
@@ -267,40 +267,92 @@ void AppendCore(const uint8_t* high, const uint8_t* low, uint8_t flags, size_t n
   if (!BrotliAppend(high, npix, out)) Fatal("Brotli", "high plane");
 }
 
-// The upstream benchmark times Encoder construction -> Finish (benchmark.cc:153-180);
-// runtime and context creation would land inside that timer, so they are done
-// when the library is loaded (FPV_NO_WARMUP=1 skips it).  Harmless without a GPU.
+// Device warm-up.  The upstream benchmark times Encoder construction -> Finish
+// (benchmark.cc:153-180): runtime and context creation (hundreds of ms once per process), the
+// first launch of each kernel (1-3 ms) and the first large transfer in either direction (~7 ms:
+// the copy engines' queues are created then) would land inside that timer.  A process that
+// merely links the library must not touch a GPU, so nothing happens at load by default:
+//   FPV_WARMUP=lazy  (default)  a helper thread parked at load time runs the warm-up when the
+//                               first Encoder / decoder object is constructed; whoever needs the
+//                               GPU first waits for it (WarmUpWait)
+//   FPV_WARMUP=eager            the warm-up runs when the library is loaded (round 2's
+//                               behaviour: the benchmark-friendly setting)
+//   FPV_WARMUP=off / FPV_NO_WARMUP=1   none
 namespace {
-struct WarmUp {
-  WarmUp() {
-    if (getenv("FPV_NO_WARMUP")) return;
-    if (fpvhip_device_count() > 0) {
-      int first = 0;
-      if (const char* e = getenv("FPV_DEVICES")) first = atoi(e);
-      if (fpvhip_warmup(first)) return;
-      // one frame through the ordinary forward and inverse entry points: the first
-      // launch of a kernel costs 1-3 ms and the first transfer of a megabyte or more in
-      // either direction ~7 ms (the copy engines' queues are created then); the common
-      // kernel variants (little-endian input with a low plane) are the ones this frame takes
-      const uint32_t wx = 1024, wy = 1024;
-      if (fpvhip_ctx* c = fpvhip_create(first, wx, wy, 4, 0, 1, 1)) {
-        std::vector<uint16_t> img((size_t)wx * wy, 0x0123);
-        for (size_t i = 0; i < img.size(); i++) img[i] = (uint16_t)((i * 37) & 0xfff);
-        const uint8_t *h, *l, *pv, *fl;
-        const uint16_t* px;
-        if (fpvhip_set_delta_raw(c, img.data()) == 0) {
-          memcpy(fpvhip_stage_in(c, 0, 0), img.data(), img.size() * 2);
-          if (fpvhip_predict_submit(c, 0, 1, 1) == 0 && fpvhip_predict_wait(c, 0, &h, &l, &pv, &fl) == 0) {
-            const uint8_t f = fl[0] | 2;  // through the speculative inverse as well
-            if (fpvhip_inverse_submit(c, 0, 1, &f) == 0) fpvhip_inverse_wait(c, 0, &px);
-          }
-        }
-        fpvhip_destroy(c);
+void WarmUpNow() {
+  if (fpvhip_device_count() <= 0) return;
+  int first = 0;
+  if (const char* e = getenv("FPV_DEVICES")) first = atoi(e);
+  if (fpvhip_warmup(first)) return;
+  // one frame through the ordinary forward and inverse entry points; the common kernel
+  // variants (little-endian input with a low plane) are the ones this frame takes
+  const uint32_t wx = 1024, wy = 1024;
+  if (fpvhip_ctx* c = fpvhip_create(first, wx, wy, 4, 0, 1, 1)) {
+    std::vector<uint16_t> img((size_t)wx * wy, 0x0123);
+    for (size_t i = 0; i < img.size(); i++) img[i] = (uint16_t)((i * 37) & 0xfff);
+    const uint8_t *h, *l, *pv, *fl;
+    const uint16_t* px;
+    if (fpvhip_set_delta_raw(c, img.data()) == 0) {
+      memcpy(fpvhip_stage_in(c, 0, 0), img.data(), img.size() * 2);
+      if (fpvhip_predict_submit(c, 0, 1, 1) == 0 && fpvhip_predict_wait(c, 0, &h, &l, &pv, &fl) == 0) {
+        const uint8_t f = fl[0] | 2;  // through the speculative inverse as well
+        if (fpvhip_inverse_submit(c, 0, 1, &f) == 0) fpvhip_inverse_wait(c, 0, &px);
       }
     }
+    fpvhip_destroy(c);
   }
-} g_warm_up;
+}
+
+struct WarmUp {
+  std::mutex m;
+  std::condition_variable cv;
+  int state = 0;  // 0 parked, 1 requested, 2 running, 3 done
+  enum Mode { kLazy, kEager, kOff } mode = kLazy;
+  WarmUp() {
+    const char* e = getenv("FPV_WARMUP");
+    if (getenv("FPV_NO_WARMUP") || (e && !strcmp(e, "off"))) mode = kOff;
+    else if (e && !strcmp(e, "eager")) mode = kEager;
+    if (mode == kOff) { state = 3; return; }
+    if (mode == kEager) state = 1;
+    std::thread([this] {  // detached: parked until somebody asks, never joined
+      std::unique_lock<std::mutex> l(m);
+      cv.wait(l, [this] { return state == 1; });
+      state = 2;
+      l.unlock();
+      WarmUpNow();
+      l.lock();
+      state = 3;
+      cv.notify_all();
+    }).detach();
+  }
+};
+WarmUp& TheWarmUp() {
+  static WarmUp* w = new WarmUp();  // leaked on purpose: the helper thread may outlive static destruction
+  return *w;
+}
+struct WarmUpAtLoad {
+  WarmUpAtLoad() { TheWarmUp(); }  // starts the (parked) helper thread; touches no GPU unless FPV_WARMUP=eager
+} g_warm_up_at_load;
 }  // namespace
+
+void WarmUpRequest() {
+  WarmUp& w = TheWarmUp();
+  std::lock_guard<std::mutex> l(w.m);
+  if (w.state == 0) {
+    w.state = 1;
+    w.cv.notify_all();
+  }
+}
+
+void WarmUpWait() {
+  WarmUp& w = TheWarmUp();
+  std::unique_lock<std::mutex> l(w.m);
+  if (w.state == 0) {
+    w.state = 1;
+    w.cv.notify_all();
+  }
+  w.cv.wait(l, [&w] { return w.state == 3; });
+}
 
 }  // namespace internal
 
@@ -353,15 +405,20 @@ struct Encoder::Impl {
 
   std::mutex m;
   std::condition_variable cv_producer;   // slot freed / in-flight count dropped
-  std::condition_variable cv_dispatch;   // batch submitted / stop
+  std::vector<std::unique_ptr<std::condition_variable>> cv_dispatch;  // [dev] batch submitted / stop
   std::condition_variable cv_work;       // tasks available / stop
   bool stop = false;
+  // First GPU failure of the session (the API is void everywhere, cc:1086-1157): latched, the
+  // session stops accepting frames, Finish emits no index.  FPV_ABORT_ON_ERROR=1: abort() instead.
+  std::atomic<bool> failed{false};
+  std::string error;
 
   std::vector<std::vector<char>> slot_busy;   // [dev][slot]
   size_t next_dev = 0;
   Batch* cur = nullptr;                       // batch being filled by the producer
   std::chrono::steady_clock::time_point cur_touched;
-  std::deque<Batch*> gpu_q;                   // submitted, waiting for the GPU
+  std::vector<std::deque<Batch*>> gpu_q;      // [dev] submitted, waiting for the GPU: one dispatcher thread per device,
+                                              // so that a slow device never delays the hand-off of the others' batches
   std::vector<std::deque<Batch*>> ready_q;    // [dev] complete batches waiting for room on the device
   std::vector<int> gpu_inflight;              // [dev] batches submitted and not yet back
   int gpu_inflight_max = 3;
@@ -377,7 +434,7 @@ struct Encoder::Impl {
   std::vector<uint64_t> offsets;              // frame index (cc:1180)
   uint64_t bytes_written = 0;
 
-  std::thread dispatcher;
+  std::vector<std::thread> dispatchers;       // [dev]
   std::vector<std::thread> workers;
 
   // Stage statistics (FPV_STATS=1: one stderr line from Finish).  Times in ns.
@@ -409,8 +466,26 @@ struct Encoder::Impl {
     }
   }
 
-  void CheckHip(int rc, fpvhip_ctx* c, const char* what) {
-    if (rc != 0) Fatal(what, fpvhip_last_error(c));
+  // Latches the session's first failure and wakes everybody up (called without the lock).
+  void Fail(const char* what, const char* detail) {
+    if (getenv("FPV_ABORT_ON_ERROR")) Fatal(what, detail);
+    {
+      std::lock_guard<std::mutex> l(m);
+      if (!failed.load()) {
+        error = std::string(what) + ": " + (detail ? detail : "");
+        fprintf(stderr, "fpv-mi355x: encoder session failed: %s (no CPU fallback exists; frames are dropped, "
+                        "Finish will emit no index; FPV_ABORT_ON_ERROR=1 aborts instead)\n", error.c_str());
+        failed.store(true);
+      }
+    }
+    cv_producer.notify_all();
+    cv_work.notify_all();
+    for (auto& cv : cv_dispatch) cv->notify_all();
+  }
+  bool CheckHip(int rc, fpvhip_ctx* c, const char* what) {
+    if (rc == 0) return true;
+    Fail(what, fpvhip_last_error(c));
+    return false;
   }
 
   // Hands a complete batch to the GPU.  Called WITHOUT the pipeline lock (the call
@@ -435,13 +510,13 @@ struct Encoder::Impl {
   }
 
   void DoSubmit(Batch* b) {
-    CheckHip(fpvhip_predict_submit(ctxs[b->dev], b->slot, b->n, 1), ctxs[b->dev],
-             "fpvhip_predict_submit");
+    if (failed.load() || !CheckHip(fpvhip_predict_submit(ctxs[b->dev], b->slot, b->n, 1), ctxs[b->dev], "fpvhip_predict_submit"))
+      return;  // the batch stays in emit_q and is freed by Finish
     st_bytes_up += (uint64_t)b->n * npix * 2;
     st_bytes_down += (uint64_t)b->n * (npix * (shift == 8 ? 1 : 2) + npv + 1);
     std::lock_guard<std::mutex> l(m);
-    gpu_q.push_back(b);
-    cv_dispatch.notify_one();
+    gpu_q[b->dev].push_back(b);
+    cv_dispatch[b->dev]->notify_one();
   }
 
   // Closes a batch (m held).  Returns true when all of its frames are staged already:
@@ -484,28 +559,45 @@ struct Encoder::Impl {
             // First touch of a slot allocates its pinned memory (tens of ms):
             // do it without the lock, the slot is already marked busy.
             l.unlock();
-            if (!fpvhip_stage_in(ctxs[d], s, 0)) Fatal("fpvhip_stage_in", fpvhip_last_error(ctxs[d]));
+            const bool staged = fpvhip_stage_in(ctxs[d], s, 0) != nullptr;
+            if (!staged) Fail("fpvhip_stage_in", fpvhip_last_error(ctxs[d]));
             l.lock();
-            emit_q.push_back(b);  // emission order = the order batches are opened in
-            return b;
+            emit_q.push_back(b);  // emission order = the order batches are opened in; owns the batch
+            return staged ? b : nullptr;
           }
         }
       }
+      if (failed.load()) return nullptr;
       cv_producer.wait(l);
     }
   }
 
-  // --- dispatcher: waits for GPU batches, fans out Brotli tasks, and flushes a
-  // partially filled batch when the producer goes quiet ---
-  void DispatchLoop() {
+  bool NoGpuBatchQueuedLocked() const {
+    for (const auto& q : gpu_q)
+      if (!q.empty()) return false;
+    return true;
+  }
+
+  // --- dispatchers, one per device: wait for that device's GPU batches in submission order and
+  // fan out their Brotli tasks; whichever is idle flushes a partially filled batch when the
+  // producer goes quiet.  (Round 2 had ONE dispatcher blocking in fpvhip_predict_wait on the
+  // head of one global queue: a late batch of one GPU delayed the hand-off of every other
+  // GPU's finished batches.) ---
+  void DispatchLoop(size_t d) {
     std::unique_lock<std::mutex> l(m);
     for (;;) {
-      if (gpu_q.empty()) {
+      if (failed.load()) {
+        gpu_q[d].clear();  // the batches stay in emit_q and are freed by Finish
+        if (stop) return;
+        cv_dispatch[d]->wait_until(l, std::chrono::system_clock::now() + std::chrono::milliseconds(20));
+        continue;
+      }
+      if (gpu_q[d].empty()) {
         if (stop) return;
         // system_clock -> pthread_cond_timedwait, which ThreadSanitizer understands
         // (clockwait is not intercepted by this toolchain); only a flush timer.
-        cv_dispatch.wait_until(l, std::chrono::system_clock::now() + std::chrono::milliseconds(2));
-        if (gpu_q.empty() && cur && cur->n > 0 &&
+        cv_dispatch[d]->wait_until(l, std::chrono::system_clock::now() + std::chrono::milliseconds(2));
+        if (NoGpuBatchQueuedLocked() && cur && cur->n > 0 &&
             std::chrono::steady_clock::now() - cur_touched > std::chrono::milliseconds(2)) {
           Batch* b = cur;
           cur = nullptr;
@@ -517,19 +609,20 @@ struct Encoder::Impl {
         }
         continue;
       }
-      Batch* b = gpu_q.front();
-      gpu_q.pop_front();
+      Batch* b = gpu_q[d].front();
+      gpu_q[d].pop_front();
       l.unlock();
       const uint64_t tw = stats ? NowNs() : 0;
-      CheckHip(fpvhip_predict_wait(ctxs[b->dev], b->slot, &b->high, &b->low, &b->pv, &b->flags),
-               ctxs[b->dev], "fpvhip_predict_wait");
-      if (stats) {
+      const bool ok = CheckHip(fpvhip_predict_wait(ctxs[b->dev], b->slot, &b->high, &b->low, &b->pv, &b->flags),
+                               ctxs[b->dev], "fpvhip_predict_wait");
+      if (ok && stats) {
         st_gpu_wait_ns += NowNs() - tw;
         const double ms = fpvhip_slot_elapsed_ms(ctxs[b->dev], b->slot);
         if (ms > 0) st_gpu_us += (uint64_t)(ms * 1000.0);
         st_batches++;
       }
       l.lock();
+      if (!ok) continue;
       b->chunks.resize(b->n);
       b->done.assign(b->n, 0);
       for (uint32_t k = 0; k < b->n; k++) work_q.push_back(Task{b, k, nullptr});
@@ -588,7 +681,15 @@ struct Encoder::Impl {
   void WorkLoop() {
     std::unique_lock<std::mutex> l(m);
     for (;;) {
-      cv_work.wait(l, [this] { return stop || !work_q.empty() || !copy_q.empty() || !prep_q.empty(); });
+      cv_work.wait(l, [this] { return stop || failed.load() || !work_q.empty() || !copy_q.empty() || !prep_q.empty(); });
+      if (failed.load()) {  // nothing of this session will be emitted any more
+        work_q.clear();
+        copy_q.clear();
+        prep_q.clear();
+        if (stop) return;
+        cv_work.wait_until(l, std::chrono::system_clock::now() + std::chrono::milliseconds(20));
+        continue;
+      }
       if (!prep_q.empty()) {
         const Prep pr = prep_q.front();
         prep_q.pop_front();
@@ -632,7 +733,7 @@ struct Encoder::Impl {
   }
 
   void StartThreads() {
-    dispatcher = std::thread(&Impl::DispatchLoop, this);
+    for (size_t d = 0; d < devices.size(); d++) dispatchers.emplace_back(&Impl::DispatchLoop, this, d);
     for (size_t i = 0; i < num_threads; i++) workers.emplace_back(&Impl::WorkLoop, this);
   }
 
@@ -641,21 +742,29 @@ struct Encoder::Impl {
       std::lock_guard<std::mutex> l(m);
       stop = true;
     }
-    cv_dispatch.notify_all();
+    for (auto& cv : cv_dispatch) cv->notify_all();
     cv_work.notify_all();
-    if (dispatcher.joinable()) dispatcher.join();
+    for (auto& t : dispatchers) t.join();
+    dispatchers.clear();
     for (auto& w : workers) w.join();
     workers.clear();
   }
 
   void ReleaseContexts() {
-    for (size_t i = 0; i < ctxs.size(); i++) ReleaseEncoderCtx(ctxs[i]);
+    for (size_t i = 0; i < ctxs.size(); i++) {
+      if (failed.load()) fpvhip_destroy(ctxs[i]);  // a context that saw an error is not cached for the next session
+      else ReleaseEncoderCtx(ctxs[i]);
+    }
     ctxs.clear();
   }
 };
 
 Encoder::Encoder(size_t num_threads, int shift_to_left_align, bool big_endian)
-    : impl_(new Impl(num_threads, shift_to_left_align, big_endian)) {}
+    : impl_(new Impl(num_threads, shift_to_left_align, big_endian)) {
+  WarmUpRequest();  // FPV_WARMUP=lazy: the device warm-up starts now, on the helper thread
+}
+
+const char* Encoder::LastError() const { return impl_->failed.load() ? impl_->error.c_str() : ""; }
 
 Encoder::~Encoder() {
   if (!impl_) return;
@@ -677,6 +786,7 @@ void Encoder::Init(const uint16_t* delta_frame, size_t xsize, size_t ysize,
                    Callback callback, void* payload) {
   Impl& s = *impl_;
   if (s.initialized) Fatal("Encoder::Init", "called twice");
+  WarmUpWait();
   const bool timing = getenv("FPV_TIMING") != nullptr;
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t_start = now();
@@ -689,15 +799,19 @@ void Encoder::Init(const uint16_t* delta_frame, size_t xsize, size_t ysize,
   const size_t cap_bytes = EnvSize("FPV_BATCH_BYTES", (size_t)256 << 20);
   s.batch = std::max<size_t>(1, std::min(s.batch_promised, cap_bytes / std::max<size_t>(1, 2 * s.npix)));
   if (s.num_threads == 0) s.slots_per_dev = 1;
+  s.initialized = true;  // from here on a failure is a latched session state, not API misuse
+  if (fpvhip_device_count() <= 0) { s.Fail("no usable GPU", fpvhip_last_error(nullptr)); return; }
   s.devices = DeviceList();
   if (s.num_threads == 0) s.devices.resize(1);
   for (int d : s.devices) {
     fpvhip_ctx* c = AcquireEncoderCtx(d, (uint32_t)xsize, (uint32_t)ysize, s.shift, s.big_endian,
                                       (uint32_t)s.batch, s.slots_per_dev);
-    if (!c) Fatal("fpvhip_create", fpvhip_last_error(nullptr));
+    if (!c) { s.Fail("fpvhip_create", fpvhip_last_error(nullptr)); return; }
     s.ctxs.push_back(c);
-    if (fpvhip_set_delta_raw(c, delta_frame)) Fatal("fpvhip_set_delta_raw", fpvhip_last_error(c));
+    if (fpvhip_set_delta_raw(c, delta_frame)) { s.Fail("fpvhip_set_delta_raw", fpvhip_last_error(c)); return; }
   }
+  s.gpu_q.assign(s.devices.size(), std::deque<Impl::Batch*>());
+  for (size_t d = 0; d < s.devices.size(); d++) s.cv_dispatch.emplace_back(new std::condition_variable());
   s.slot_busy.assign(s.devices.size(), std::vector<char>(s.slots_per_dev, 0));
   s.slot_prepared.assign(s.devices.size(), std::vector<char>(s.slots_per_dev, 0));
   s.ready_q.assign(s.devices.size(), std::deque<Impl::Batch*>());
@@ -709,10 +823,13 @@ void Encoder::Init(const uint16_t* delta_frame, size_t xsize, size_t ysize,
   // The delta frame itself: predicted WITHOUT a delta frame (cc:1099-1100),
   // written as header | u32 size | 0x01 | image core (cc:1092-1103).
   fpvhip_ctx* c0 = s.ctxs[0];
-  memcpy(fpvhip_stage_in(c0, 0, 0), delta_frame, s.npix * 2);
-  s.CheckHip(fpvhip_predict_submit(c0, 0, 1, 0), c0, "fpvhip_predict_submit");
+  uint16_t* stage0 = fpvhip_stage_in(c0, 0, 0);
+  if (!stage0) { s.Fail("fpvhip_stage_in", fpvhip_last_error(c0)); return; }
+  memcpy(stage0, delta_frame, s.npix * 2);
   const uint8_t *high, *low, *pv, *flags;
-  s.CheckHip(fpvhip_predict_wait(c0, 0, &high, &low, &pv, &flags), c0, "fpvhip_predict_wait");
+  if (!s.CheckHip(fpvhip_predict_submit(c0, 0, 1, 0), c0, "fpvhip_predict_submit") ||
+      !s.CheckHip(fpvhip_predict_wait(c0, 0, &high, &low, &pv, &flags), c0, "fpvhip_predict_wait"))
+    return;
   const double t_pred = now();
   std::vector<uint8_t> out;
   out.reserve(s.npix + 64);
@@ -720,7 +837,6 @@ void Encoder::Init(const uint16_t* delta_frame, size_t xsize, size_t ysize,
   Append32((uint32_t)ysize, &out);
   Append32(0, &out);
   out.push_back(1);
-  s.initialized = true;
   if (s.num_threads > 0) {
     s.StartThreads();  // the workers spawn while the delta frame is compressed ...
     std::lock_guard<std::mutex> l(s.m);
@@ -759,13 +875,15 @@ void Encoder::Init(const uint16_t* delta_frame, size_t xsize, size_t ysize,
 void Encoder::CompressFrame(const uint16_t* img, Callback callback, void* payload) {
   Impl& s = *impl_;
   if (!s.initialized || s.finished) Fatal("Encoder::CompressFrame", "Init not called or already finished");
+  if (s.failed.load()) return;  // latched failure: the frame is dropped, its callback never runs (LastError)
 
   if (s.num_threads == 0) {  // synchronous path (cc:1136-1141)
     fpvhip_ctx* c = s.ctxs[0];
     memcpy(fpvhip_stage_in(c, 0, 0), img, s.npix * 2);
-    s.CheckHip(fpvhip_predict_submit(c, 0, 1, 1), c, "fpvhip_predict_submit");
     const uint8_t *high, *low, *pv, *flags;
-    s.CheckHip(fpvhip_predict_wait(c, 0, &high, &low, &pv, &flags), c, "fpvhip_predict_wait");
+    if (!s.CheckHip(fpvhip_predict_submit(c, 0, 1, 1), c, "fpvhip_predict_submit") ||
+        !s.CheckHip(fpvhip_predict_wait(c, 0, &high, &low, &pv, &flags), c, "fpvhip_predict_wait"))
+      return;
     std::vector<uint8_t> chunk;
     BuildFrameChunk(high, low, pv, flags[0], s.npix, s.npv, &chunk);
     s.offsets.push_back(s.bytes_written);
@@ -777,6 +895,7 @@ void Encoder::CompressFrame(const uint16_t* img, Callback callback, void* payloa
 
   std::unique_lock<std::mutex> l(s.m);
   if (!s.cur) s.cur = s.OpenBatchLocked(l);
+  if (!s.cur) return;  // the session failed while waiting for a slot
   Impl::Batch* b = s.cur;
   // The pixels are copied into pinned staging by a worker thread: the caller
   // keeps `img` alive until this frame's callback, as the API demands.
@@ -798,7 +917,7 @@ void Encoder::CompressFrame(const uint16_t* img, Callback callback, void* payloa
       l.lock();
     }
   }
-  s.cv_producer.wait(l, [&s] { return s.inflight < s.max_queued; });  // cc:1150-1156
+  s.cv_producer.wait(l, [&s] { return s.inflight < s.max_queued || s.failed.load(); });  // cc:1150-1156
 }
 
 void Encoder::Finish(Callback callback, void* payload) {
@@ -808,7 +927,7 @@ void Encoder::Finish(Callback callback, void* payload) {
   if (s.num_threads > 0) {
     {
       std::unique_lock<std::mutex> l(s.m);
-      if (s.cur) {
+      if (s.cur && !s.failed.load()) {
         Impl::Batch* b = s.cur;
         s.cur = nullptr;
         if (s.CloseLocked(b)) {  // never empty: a batch is opened by its first frame
@@ -817,11 +936,17 @@ void Encoder::Finish(Callback callback, void* payload) {
           l.lock();
         }
       }
-      s.cv_producer.wait(l, [&s] { return s.inflight == 0 && s.emit_q.empty(); });
+      s.cv_producer.wait(l, [&s] { return (s.inflight == 0 && s.emit_q.empty()) || s.failed.load(); });
     }
     s.StopThreads();
   }
   s.finished = true;
+  if (s.failed.load()) {  // no index: the stream ends with the last chunk that was emitted
+    for (Impl::Batch* b : s.emit_q) delete b;
+    s.emit_q.clear();
+    s.ReleaseContexts();
+    return;
+  }
   s.ReleaseContexts();
   // frame index (cc:1185-1197)
   const size_t n = s.offsets.size();

@@ -37,6 +37,11 @@ bool BrotliInto(const uint8_t* in, size_t size, size_t* pos, uint8_t* dst,
 // Brotli of the planes of a batch, in both directions -- do not pay for thread creation.
 void ParallelFor(size_t n, size_t threads, const std::function<void(size_t)>& fn);
 
+// Device warm-up (fpv_host.cc): Request starts it on the helper thread if it has not run yet
+// (object constructors), Wait also blocks until it is done (whoever is about to create a context).
+void WarmUpRequest();
+void WarmUpWait();
+
 std::vector<int> DeviceList();
 size_t EnvSize(const char* name, size_t dflt);
 

@@ -26,6 +26,9 @@ void fpvc_encoder_finish(void *enc, fpvc_write_fn cb, void *payload);
 void fpvc_encoder_free(void *enc);
 /* Encoder::LastStats (extension): stage statistics after Finish; see fusion_power_video.h. */
 size_t fpvc_encoder_stats(const void *enc, double *out, size_t n);
+/* Encoder::LastError (extension): the session's first GPU failure, "" while there is none.  After a
+ * failure the session drops further frames and fpvc_encoder_finish emits no index. */
+const char *fpvc_encoder_last_error(const void *enc);
 /*
  * Benchmark helper: Encoder construction -> Finish over `total` frames cycling through
  * `distinct` resident ones (frame 0 doubles as the delta frame, as encode.cc does), timed

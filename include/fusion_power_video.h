@@ -77,6 +77,13 @@ class Frame {
   Frame(size_t xsize, size_t ysize, uint8_t flags, uint8_t state,
         std::vector<uint8_t>&& high, std::vector<uint8_t>&& low,
         std::vector<uint8_t>&& preview, int64_t timestamp = -1);
+  // Copies synchronise with the lazy split of the source (a RAW frame shared as the delta
+  // frame may be split by another thread's high() / flags() at any time); moves are the
+  // owner's business, as upstream.
+  Frame(const Frame& other);
+  Frame& operator=(const Frame& other);
+  Frame(Frame&&) = default;
+  Frame& operator=(Frame&&) = default;
 
   size_t xsize() const { return xsize_; }
   size_t ysize() const { return ysize_; }
@@ -125,6 +132,7 @@ class Frame {
   uint64_t content_id_ = 0;  // changes whenever the planes change; copies share it
   mutable int planes_pending_ = 0;  // read / written atomically: a shared delta frame may be split by any thread
   bool PlanesPending() const { return __atomic_load_n(&planes_pending_, __ATOMIC_ACQUIRE) != 0; }
+  void CopyFrom(const Frame& other);
   void SplitNow() const;     // the first constructor's split (cc:370-451), on the GPU; thread-safe
   void Touch();              // SplitNow if pending + a new content id
 };
@@ -198,6 +206,11 @@ class Encoder {
   // (Brotli + copies, per thread) / wall, [9] ms the dispatcher waited for the GPU.
   // Returns the number of values written (at most n).
   size_t LastStats(double* out, size_t n) const;
+  // Extension: the session's first GPU failure ("" while there is none).  The upstream API is
+  // void everywhere; after a failure the session accepts no more frames (their callbacks never
+  // run), Finish emits no frame index, and the process goes on.  FPV_ABORT_ON_ERROR=1 makes
+  // such a failure abort() instead.
+  const char* LastError() const;
 
  private:
   struct Impl;

@@ -9,12 +9,23 @@
  * libraries never see it and have no CPU path.  The device-resident entry
  * points fail here.
  */
+#define _POSIX_C_SOURCE 200809L
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "fpv_hip.h"
 #include "fpv_oracle.h"
+
+/* Test knobs (environment, read per call):
+ *   FPV_SHIM_DEVICES=N        pose as N devices
+ *   FPV_SHIM_DELAY=<dev>:<ms> fpvhip_predict_wait on contexts of device <dev> sleeps <ms> first
+ *                             (a slow GPU); fpvhip_shim_overlapped_waits() counts the waits of
+ *                             OTHER devices that returned while such a sleep was in progress
+ *   FPV_SHIM_FAIL_WAIT=<k>    the k-th fpvhip_predict_wait made while the variable is set (1-based) fails */
+static int g_delayed_active, g_overlapped, g_waits;
+int fpvhip_shim_overlapped_waits(void) { return __atomic_load_n(&g_overlapped, __ATOMIC_SEQ_CST); }
 
 typedef struct {
   uint16_t *pix;
@@ -25,7 +36,7 @@ typedef struct {
 struct fpvhip_ctx {
   uint32_t xs, ys, batch, nslots;
   size_t npix, npv;
-  int shift, be, fwd_ok, have_delta;
+  int shift, be, fwd_ok, have_delta, device;
   uint8_t *dhigh, *dlow;
   uint16_t *d16;
   slot_t *slots;
@@ -79,8 +90,9 @@ static fpvhip_ctx *mk(uint32_t xs, uint32_t ys, int shift, int be, uint32_t batc
 
 fpvhip_ctx *fpvhip_create(int device, uint32_t xs, uint32_t ys, int shift, int be,
                           uint32_t batch, uint32_t slots) {
-  (void)device;
-  return mk(xs, ys, shift, be, batch, slots, 1);
+  fpvhip_ctx *c = mk(xs, ys, shift, be, batch, slots, 1);
+  if (c) c->device = device;
+  return c;
 }
 fpvhip_ctx *fpvhip_create_decoder(int device, uint32_t xs, uint32_t ys, uint32_t batch,
                                   uint32_t slots) {
@@ -153,6 +165,22 @@ int fpvhip_predict_submit(fpvhip_ctx *c, uint32_t slot, uint32_t n, int with_del
 int fpvhip_predict_wait(fpvhip_ctx *c, uint32_t slot, const uint8_t **high,
                         const uint8_t **low, const uint8_t **pv, const uint8_t **flags) {
   slot_t *s = &c->slots[slot];
+  const char *e;
+  int delayed = 0;
+  if ((e = getenv("FPV_SHIM_FAIL_WAIT")) && __atomic_add_fetch(&g_waits, 1, __ATOMIC_SEQ_CST) == atoi(e)) {
+    snprintf(c->err, sizeof c->err, "injected failure of fpvhip_predict_wait (FPV_SHIM_FAIL_WAIT)");
+    return -1;
+  }
+  if ((e = getenv("FPV_SHIM_DELAY")) && atoi(e) == c->device && strchr(e, ':')) {
+    struct timespec ts;
+    const long ms = atol(strchr(e, ':') + 1);
+    ts.tv_sec = ms / 1000; ts.tv_nsec = (ms % 1000) * 1000000L;
+    delayed = 1;
+    __atomic_add_fetch(&g_delayed_active, 1, __ATOMIC_SEQ_CST);
+    nanosleep(&ts, NULL);
+    __atomic_sub_fetch(&g_delayed_active, 1, __ATOMIC_SEQ_CST);
+  }
+  if (!delayed && __atomic_load_n(&g_delayed_active, __ATOMIC_SEQ_CST) > 0) __atomic_add_fetch(&g_overlapped, 1, __ATOMIC_SEQ_CST);
   if (!s->pending) { snprintf(c->err, sizeof c->err, "nothing in flight"); return -1; }
   s->pending = 0;
   if (high) *high = s->high;

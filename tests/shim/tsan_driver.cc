@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -153,6 +154,41 @@ int main() {
     for (auto& th : pool) th.join();
     if (bad) return 40;
     printf("concurrent Frame::Predict ok\n");
+  }
+  {
+    // Eight devices with one dispatcher thread each, device 3 slow: the other seven hand their
+    // batches to the workers while its wait sleeps; emission stays in order, bytes unchanged.
+    const size_t xs = 64, ys = 48, n = 128;
+    std::vector<uint16_t> fr(n * xs * ys);
+    uint32_t s = 991;
+    for (auto& v : fr) { s = s * 1664525u + 1013904223u; v = (s >> 16) & 0xfff; }
+    setenv("FPV_BATCH", "4", 1);
+    auto encode = [&](std::vector<uint8_t>* out, std::string* err) {
+      fpvc::Encoder enc(4, 4, false);
+      enc.Init(fr.data(), xs, ys, Append, out);
+      for (size_t i = 0; i < n; i++) enc.CompressFrame(&fr[i * xs * ys], Append, out);
+      enc.Finish(Append, out);
+      *err = enc.LastError();
+    };
+    std::vector<uint8_t> one, eight, failed;
+    std::string e1, e8, ef;
+    setenv("FPV_SHIM_DEVICES", "1", 1);
+    encode(&one, &e1);
+    setenv("FPV_SHIM_DEVICES", "8", 1);
+    setenv("FPV_SHIM_DELAY", "3:15", 1);
+    encode(&eight, &e8);
+    unsetenv("FPV_SHIM_DELAY");
+    if (one != eight || !e1.empty() || !e8.empty()) return 50;
+    printf("eight devices, one slow: ok\n");
+    // a failing wait in the middle of a session: latched, no index, nothing hangs
+    setenv("FPV_SHIM_DEVICES", "2", 1);
+    setenv("FPV_SHIM_FAIL_WAIT", "4", 1);   // counts the waits from here on: the knob is read per call
+    encode(&failed, &ef);
+    unsetenv("FPV_SHIM_FAIL_WAIT");
+    unsetenv("FPV_BATCH");
+    if (ef.empty() || failed.size() >= one.size() || failed.empty()) return 51;
+    if (memcmp(failed.data(), one.data(), failed.size()) != 0) return 52;  // a clean prefix of the stream
+    printf("latched GPU failure: ok\n");
   }
   return 0;
 }

@@ -207,6 +207,78 @@ print("DECODE ok")
     assert shas[0] == shas[1] == shas[2]
 
 
+_PIPE_SCRIPT = r'''
+import sys, os, importlib, hashlib, ctypes, time
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+from conftest import load_package
+load_package()
+synth = importlib.import_module("fpv_amd.synth"); codec = importlib.import_module("fpv_amd.codec").Codec(sys.argv[2])
+fr = synth.noise_frames(int(sys.argv[3]), 64, 48, seed=9)
+t0 = time.time()
+mq, got = codec.encode_with_callbacks(fr, fr[0], 64, 48, threads=int(sys.argv[4]))
+dt = time.time() - t0
+ids = [int(p) for p, _ in got]
+print("IDS", " ".join(map(str, ids)))
+print("SHA", hashlib.sha256(b"".join(b for _, b in got)).hexdigest())
+print("ERR", codec.last_error)
+print("SECONDS %.3f" % dt)
+lib = ctypes.CDLL(os.path.join(os.path.dirname(sys.argv[2]), "libfpv_amd_cpushim.so"))
+if hasattr(lib, "fpvhip_shim_overlapped_waits"):
+    print("OVERLAPPED", lib.fpvhip_shim_overlapped_waits())
+'''
+
+
+def _run_pipe(tmp_path, env, nframes=160, threads=4):
+    import subprocess
+    import sys
+    script = tmp_path / "pipe.py"
+    script.write_text(_PIPE_SCRIPT)
+    out = subprocess.run([sys.executable, str(script), os.path.dirname(HERE), SHIM, str(nframes), str(threads)],
+                         env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    return {l.split(" ", 1)[0]: l.split(" ", 1)[1] if " " in l else "" for l in out.stdout.splitlines() if l[:1].isupper()}, out.stderr
+
+
+def test_slow_device_does_not_block_the_others(tmp_path):
+    """Eight devices, one of them slow (cc:1217-1224 keeps the EMISSION in order; nothing says the
+    hand-off of finished GPU batches has to be).  One dispatcher per device: while the slow
+    device's fpvhip_predict_wait is still sleeping, the waits of the other seven return and their
+    batches go to the Brotli workers.  A single FIFO dispatcher (round 2) would show zero such
+    overlaps.  Emission order and bytes are those of one device."""
+    if not os.path.exists(SHIM):
+        pytest.skip("tests/shim not built")
+    base, _ = _run_pipe(tmp_path, {"FPV_SHIM_DEVICES": "1", "FPV_BATCH": "4"})
+    slow, _ = _run_pipe(tmp_path, {"FPV_SHIM_DEVICES": "8", "FPV_SHIM_DELAY": "3:40", "FPV_BATCH": "4"})
+    assert slow["SHA"] == base["SHA"]
+    ids = [int(v) for v in slow["IDS"].split()]
+    assert ids == [1000000] + list(range(1, 161)) + [2000000]        # header, frames in order, index
+    assert int(slow["OVERLAPPED"]) > 0
+    assert slow["ERR"] == ""
+
+
+def test_gpu_failure_is_latched_not_fatal(tmp_path):
+    """A failing fpvhip_predict_wait in the middle of a session (a lost device): the process goes
+    on, the frames of batches before the failure have been emitted in order, later ones are
+    dropped, Finish emits NO index, Encoder::LastError tells why.  FPV_ABORT_ON_ERROR=1 keeps
+    round 2's abort()."""
+    import subprocess
+    import sys
+    if not os.path.exists(SHIM):
+        pytest.skip("tests/shim not built")
+    res, err = _run_pipe(tmp_path, {"FPV_SHIM_DEVICES": "2", "FPV_SHIM_FAIL_WAIT": "6", "FPV_BATCH": "4"})
+    ids = [int(v) for v in res["IDS"].split()]
+    assert ids[0] == 1000000 and 2000000 not in ids and 3000000 not in ids   # header, but no index
+    frames = ids[1:]
+    assert frames == list(range(1, len(frames) + 1)) and 0 < len(frames) < 160   # a clean prefix, in order
+    assert "injected failure" in res["ERR"] and "encoder session failed" in err
+    # the old behaviour on request
+    script = tmp_path / "pipe.py"
+    out = subprocess.run([sys.executable, str(script), os.path.dirname(HERE), SHIM, "40", "4"],
+                         env=dict(os.environ, FPV_SHIM_FAIL_WAIT="3", FPV_BATCH="4", FPV_ABORT_ON_ERROR="1"),
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "fatal" in out.stderr
+
+
 def test_fuzzed_streams_never_crash(codec):
     """Random byte flips, truncations and splices: every decoder entry either
     succeeds or reports failure; none may crash or read out of bounds."""

@@ -18,4 +18,6 @@ def test_threadsanitizer_host_pipeline():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert r.stdout.count(" ok, ") == 4 and "concurrent sessions ok" in r.stdout
     assert "concurrent DecodeFrames on one decoder ok" in r.stdout   # used to deadlock (two slots per engine)
+    assert "eight devices, one slow: ok" in r.stdout                 # one dispatcher thread per device
+    assert "latched GPU failure: ok" in r.stdout                     # Encoder::LastError instead of abort()
     assert r.stdout.count("columnar ok") == 5   # the columnar adapter's queues and futures

@@ -313,7 +313,11 @@ struct WarmUp {
     if (getenv("FPV_NO_WARMUP") || (e && !strcmp(e, "off"))) mode = kOff;
     else if (e && !strcmp(e, "eager")) mode = kEager;
     if (mode == kOff) { state = 3; return; }
-    if (mode == kEager) state = 1;
+    if (mode == kEager) {  // at load, before main(): nothing of it lands in anybody's timer
+      WarmUpNow();
+      state = 3;
+      return;
+    }
     std::thread([this] {  // detached: parked until somebody asks, never joined
       std::unique_lock<std::mutex> l(m);
       cv.wait(l, [this] { return state == 1; });

@@ -2644,13 +2644,12 @@ hipError_t launch_predict(const Geom& g, const uint16_t* d_frames,
 // Frames whose three-wave workgroups (k_inverse_trio) are all resident at the same time on
 // the current device: workgroups per CU as the runtime's occupancy query sees them (register
 // and LDS budget of the instantiation for this geometry) times the CUs.  Cached per device / K4.
-static uint32_t trio_capacity(const Geom& g) {
+static uint32_t trio_capacity(const Geom& g, uint32_t k4) {
   static std::mutex m;
   static uint32_t cap[64][kSpecMaxK4 + 1] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) dev = 0;
   dev &= 63;
-  const uint32_t k4 = g.spec_k4;
   if (k4 == 0 || k4 > kSpecMaxK4) return 0;
   std::lock_guard<std::mutex> l(m);
   if (!cap[dev][k4]) {
@@ -2669,20 +2668,31 @@ static uint32_t trio_capacity(const Geom& g) {
 }
 
 // Which inverse kernel a batch of nframes takes: 3 three waves per frame, 0 one wave per
-// frame (speculative), 1 the serial-chain kernel, 2 the byte-granular one.
-static int inverse_mode(const Geom& g, uint32_t nframes) {
+// frame (speculative), 1 the serial-chain kernel, 2 the byte-granular one; *k4 = the segment
+// length (dwords per lane and superstep) the speculative kernels run with.
+// Three waves per frame as long as EVERY frame's workgroup is resident at the same time: at the
+// geometry's own k4 (1024 frames at 1280x800 on MI355X) or, for batches just beyond that, at
+// k4 - 1 (shorter supersteps, fewer registers: five workgroups per CU instead of four, 1280
+// frames; 1100 frames 1.18 ms against 1.36 with one wave per frame, profiles/r03_inverse_sizes.log).
+static int inverse_mode(const Geom& g, uint32_t nframes, uint32_t* k4) {
   int mode = -1;  // the environment is read per launch: tests switch kernels inside one process
+  *k4 = g.spec_k4;
   if (getenv("FPV_INVERSE_SLOW")) {
     mode = 2;
   } else if (const char* e = getenv("FPV_INVERSE")) {
     mode = e[0] == 'f' ? 1 : e[0] == 's' && e[1] == 'l' ? 2 : e[0] == 's' ? 0 : e[0] == 't' ? 3 : -1;
   }
-  if (mode < 0) mode = g.spec_k4 && nframes <= trio_capacity(g) ? 3 : 0;
+  if (mode < 0) {
+    mode = 0;
+    if (g.spec_k4 && nframes <= trio_capacity(g, g.spec_k4)) mode = 3;
+    else if (g.spec_k4 > 1 && nframes <= trio_capacity(g, g.spec_k4 - 1)) { mode = 3; *k4 = g.spec_k4 - 1; }
+  }
   return mode;
 }
 
 const char* inverse_kernel_name(const Geom& g, uint32_t nframes) {
-  const int mode = inverse_mode(g, nframes);
+  uint32_t k4;
+  const int mode = inverse_mode(g, nframes, &k4);
   const bool aligned = (g.xs & 3) == 0 && (g.npix & 3) == 0;
   if (mode == 3 && g.spec_k4) return "k_inverse_trio";
   if (mode == 0 && g.spec_k4) return "k_inverse_spec";
@@ -2703,7 +2713,8 @@ hipError_t launch_inverse(const Geom& g, const uint8_t* d_high,
   // four such workgroups per CU); beyond that a second round of workgroups would run nearly
   // alone, and one wave per frame (more frames resident, less synchronisation) wins:
   // 1100 frames 1.35 ms against 1.56, 2000 frames 1.65 against 2.28 (profiles/r02_inverse_ab.log).
-  const int mode = inverse_mode(g, nframes);
+  uint32_t k4;
+  const int mode = inverse_mode(g, nframes, &k4);
   const bool aligned = (g.xs & 3) == 0 && (g.npix & 3) == 0;
   if (mode == 3 && g.spec_k4) {
 #define FPV_LAUNCH_TRIO(K4)                                                                     \
@@ -2711,7 +2722,7 @@ hipError_t launch_inverse(const Geom& g, const uint8_t* d_high,
     k_inverse_trio<K4><<<nframes, 192, g.spec_ring + 10 * 256 * K4, s>>>(                       \
         d_high, d_low, d_dhigh, d_dlow, d_flags, d_frames, g, d_diag);                          \
     break;
-    switch (g.spec_k4) {
+    switch (k4) {
       FPV_LAUNCH_TRIO(1) FPV_LAUNCH_TRIO(2) FPV_LAUNCH_TRIO(3)
       FPV_LAUNCH_TRIO(4) FPV_LAUNCH_TRIO(5) FPV_LAUNCH_TRIO(6)
       default: return hipErrorInvalidValue;
@@ -2723,7 +2734,7 @@ hipError_t launch_inverse(const Geom& g, const uint8_t* d_high,
     k_inverse_spec<K4><<<nframes, 64, g.spec_ring, s>>>(d_high, d_low, d_dhigh, d_dlow,      \
                                                         d_flags, d_frames, g, d_diag);       \
     break;
-    switch (g.spec_k4) {
+    switch (k4) {
       FPV_LAUNCH_SPEC(1) FPV_LAUNCH_SPEC(2) FPV_LAUNCH_SPEC(3)
       FPV_LAUNCH_SPEC(4) FPV_LAUNCH_SPEC(5) FPV_LAUNCH_SPEC(6)
       default: return hipErrorInvalidValue;

@@ -74,6 +74,15 @@ while time.time() - t0 < budget:
         fr[1:] = fr[0]          # frames equal to the delta frame
     delta = fr[0] if rng.integers(0, 5) else None
     os.environ["FPV_INVERSE"] = str(rng.choice(["spec", "trio", "auto", "fast"], p=[0.4, 0.4, 0.1, 0.1]))  # read per launch
+    # forward path (read when the context is created): the tile pass with a random tile height where the
+    # width allows it (multiples of 64), now and then the streaming kernels instead
+    os.environ.pop("FPV_TILE_GROUPS", None)
+    os.environ.pop("FPV_FORWARD", None)
+    r = int(rng.integers(0, 8))
+    if r == 0:
+        os.environ["FPV_FORWARD"] = "stream"
+    elif r < 4:
+        os.environ["FPV_TILE_GROUPS"] = str(int(rng.integers(1, 24)))
     p = pkg.Predictor(xs, ys, shift, be, max_batch=n)
     if delta is not None:
         p.set_delta_raw(delta)
@@ -94,6 +103,14 @@ while time.time() - t0 < budget:
             print("PREDICT MISMATCH", tag, "frame", k, flush=True)
             sys.exit(1)
         seen_flags.add(int(ef))
+    # a second and third batch of the same frames: now under the flags prediction the first ones left
+    # behind (per batch position); the planes must not change
+    for _ in range(2):
+        h2, l2, p2, f2 = p.predict(d, with_delta=delta is not None)
+        torch.cuda.synchronize()
+        if not (torch.equal(h2, high) and torch.equal(p2, pv) and torch.equal(f2, flags) and (shift == 8 or torch.equal(l2, low))):
+            print("REPEATED BATCH MISMATCH", tag, flush=True)
+            sys.exit(1)
     rec = p.inverse(high, low, flags)
     # inverse on arbitrary planes with every flag combination that is legal here
     rh = torch.from_numpy(rng.integers(0, 256, H.shape, dtype=np.uint8)).cuda()

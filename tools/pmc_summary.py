@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
 """Summarises rocprofv3 --pmc CSVs (tools/prof_pmc.sh) per kernel: mean counter
 value per dispatch.  usage: pmc_summary.py gpurun_out/pmc_<tag> [kernel-substring]"""
-import csv, glob, os, sys, collections, json
+import csv, glob, os, re, sys, collections, json
 root = sys.argv[1]
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0].split("::")[-1]
+        m = re.search(r"\b(k_[a-z0-9_]+)", r["Kernel_Name"])   # "void fpvhip::(anonymous namespace)::k_tile<false, true>(...)"
+        k = m.group(1) if m else r["Kernel_Name"][:40]
         if flt in r["Kernel_Name"]:
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {}

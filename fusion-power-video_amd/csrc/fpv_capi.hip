@@ -741,7 +741,7 @@ double fpvhip_slot_elapsed_ms(fpvhip_ctx* c, uint32_t slot) {
 
 const char* fpvhip_forward_kernel_names(fpvhip_ctx* c) {
   if (!c || !c->g.fwd_ok) return "";
-  return c->g.tile_ok ? "k_tile,k_tile_decide,k_redo_tiles" : "k_stream,k_redo_decide,k_redo_stream";
+  return c->g.tile_ok ? "k_tile,k_tile_decide,k_tile_finish" : "k_stream,k_redo_decide,k_redo_stream";
 }
 
 const char* fpvhip_inverse_kernel_name(fpvhip_ctx* c, uint32_t nframes) {

@@ -2331,10 +2331,11 @@ bool make_geom(uint32_t xs, uint32_t ys, int shift, int big_endian, Geom* g,
   {
     const uint32_t ncs = xs / 16;
     // Workgroup sizes that fill the CU's wave slots evenly at this kernel's register budget (16
-    // waves per CU): 512 threads where that gives at least 4 groups, else 1024 (measured at
-    // 1280x800: G = 6 / 512 threads 0.72 ms, G = 4 / 320 threads 0.88, G = 8 / 640 threads 1.0).
+    // waves per CU): 512 threads where that gives at least 2 groups, else 1024 (measured at
+    // 1280x800: G = 6 / 512 threads 0.72 ms, G = 4 / 320 threads 0.88, G = 8 / 640 threads 1.0;
+    // at 4096x4096: G = 2 / 512 threads 0.895 ms per 60 frames, G = 4 / 1024 threads 0.965).
     uint32_t G = ncs ? 512u / ncs : 0;
-    if (G < 4 && ncs) G = 1024u / ncs;
+    if (G < 2 && ncs) G = 1024u / ncs;
     if (const char* e = getenv("FPV_TILE_GROUPS")) G = std::max(1u, (uint32_t)atoi(e));
     if (ncs && G * ncs > 1024) G = 1024 / ncs;
     G = std::min(G, ys / 4);
@@ -2556,11 +2557,12 @@ static hipError_t predict_impl(const Geom& g, const uint16_t* d_frames,
     if (lowp) k_tile<SWAP, true><<<nframes * g.tile_tiles, T, lds, s>>>(L);
     else k_tile<SWAP, false><<<nframes * g.tile_tiles, T, lds, s>>>(L);
     if (ev) hipEventRecord(ev[1], s);
-    k_tile_decide<SWAP><<<nframes, kDecideThreads, 0, s>>>(L);
+    if (g.tile_tiles > 64) k_tile_decide<SWAP, true><<<nframes, 1024, 0, s>>>(L);   // many records per frame (large frames)
+    else k_tile_decide<SWAP, false><<<nframes, 256, 0, s>>>(L);
     if (ev) hipEventRecord(ev[2], s);
     const uint32_t rgrid = std::min<uint32_t>(nframes * g.tile_tiles, device_cus() * std::max(1u, 2048u / T));
-    if (lowp) k_redo_tiles<SWAP, true><<<rgrid, T, lds, s>>>(L);
-    else k_redo_tiles<SWAP, false><<<rgrid, T, lds, s>>>(L);
+    if (lowp) k_tile_finish<SWAP, true><<<rgrid, T, lds, s>>>(L);
+    else k_tile_finish<SWAP, false><<<rgrid, T, lds, s>>>(L);
     if (ev) hipEventRecord(ev[3], s);
     if (ev) hipEventRecord(ev[4], s);
     return hipGetLastError();

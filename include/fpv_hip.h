@@ -226,7 +226,7 @@ int fpvhip_inverse_pass_stats(fpvhip_ctx *ctx, uint32_t *out, int reset);
  * ("k_inverse_trio", "k_inverse_spec", "k_inverse_fast", "k_inverse"). */
 const char *fpvhip_inverse_kernel_name(fpvhip_ctx *ctx, uint32_t nframes);
 /* Diagnostics: the three launches of one forward batch on this context, comma separated
- * ("k_tile,k_tile_decide,k_redo_tiles" for the tile pass, "k_stream,k_redo_decide,k_redo_stream"
+ * ("k_tile,k_tile_decide,k_tile_finish" for the tile pass, "k_stream,k_redo_decide,k_redo_stream"
  * for geometries that keep the streaming kernels): the order of kernel_ms[] of
  * fpvhip_time_predict_device. */
 const char *fpvhip_forward_kernel_names(fpvhip_ctx *ctx);

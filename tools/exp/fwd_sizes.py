@@ -1,0 +1,26 @@
+"""Forward-kernel time at other geometries (experiments): python tools/exp/fwd_sizes.py
+For each geometry: the tile pass at its default tile height, other heights, and the streaming kernels
+(FPV_FORWARD=stream), same frames, same process.  GB/s = algorithmic bytes (4.0625 P per frame)."""
+import sys, os, importlib, numpy as np, torch
+sys.path.insert(0, '.')
+from __graft_entry__ import load_package
+pkg = load_package(); synth = importlib.import_module('fpv_amd.synth')
+cases = [(1920, 1080, 480, 0, 16), (4096, 4096, 60, 0, 16), (256, 256, 8000, 0, 16), (1024, 1024, 1000, 4, 12), (2048, 1536, 320, 4, 12), (1280, 800, 1000, 4, 12)]
+for xs, ys, n, shift, bits in cases:
+    base = synth.plasma_frames(9, xs, ys, bits=bits, seed=3)
+    d = torch.from_numpy(base[1:].reshape(8, -1).view(np.int16)).cuda()
+    fr = d[torch.arange(n, device='cuda') % 8].contiguous().view(torch.uint16)
+    out = None
+    for env in ({}, {"FPV_TILE_GROUPS": "1"}, {"FPV_TILE_GROUPS": "2"}, {"FPV_TILE_GROUPS": "3"}, {"FPV_TILE_GROUPS": "8"}, {"FPV_FORWARD": "stream"}):
+        os.environ.update(env)
+        p = pkg.Predictor(xs, ys, shift, False, max_batch=n); p.set_delta_raw(base[0])
+        for k in env: os.environ.pop(k)
+        out = out or p.alloc_outputs(n)
+        for _ in range(3): p.predict(fr, out=out)
+        torch.cuda.synchronize()
+        ms = min(p.time_predict(fr, out, 10) / 10 for _ in range(3))
+        _, km = p.time_predict(fr, out, 5, per_kernel=True)
+        print(f"{xs}x{ys} n={n} {str(env):28s} {p.forward_kernel_names()[0]:9s} {ms:.4f} ms/batch  kernels {[round(k,4) for k in km[:3]]}  {n*xs*ys*4.0625/ms/1e6:.0f} GB/s all kernels, {n*xs*ys*4.0625/km[0]/1e6:.0f} dominant", flush=True)
+        p.close()
+    del fr, out, d
+    torch.cuda.empty_cache()

@@ -52,3 +52,33 @@ def test_bench_line_contract():
         assert k in cb, k
     assert cb["kind"] in ("reference", "port") and cb["cores"] == 1 and cb["value"] > 0
     assert d["inverse"]["roundtrip_bit_exact"] is True
+
+
+def test_forward_rate_does_not_depend_on_where_the_buffers_lie(fpv, synth):
+    """Round 2's headline was measured on the best of sixteen buffer placements (its streaming
+    kernel moved by up to 10 % with the location of the buffers in HBM) -- something no product
+    context ever did.  bench.py now measures the first allocation; this test pins why that is
+    fair: two contexts (each with its own workspace), three independently allocated buffer sets
+    each, same 1000-frame batch -- the tile pass's time per batch stays within a few percent."""
+    import numpy as np
+    import torch
+    xs, ys, n = 1280, 800, 1000
+    base = synth.plasma_frames(64, xs, ys, bits=12, seed=7)
+    d = torch.from_numpy(base.reshape(64, -1).view(np.int16)).cuda()
+    idx = torch.arange(n, device="cuda") % 64
+    times = []
+    keep = []   # hold every set until the end: each lies somewhere else
+    for _ in range(2):
+        p = fpv.Predictor(xs, ys, 4, False, max_batch=n)
+        p.set_delta_raw(base[0])
+        for _ in range(3):
+            fr = d[idx].contiguous().view(torch.uint16)
+            out = p.alloc_outputs(n)
+            for _ in range(3):
+                p.predict(fr, out=out)
+            torch.cuda.synchronize()
+            times.append(min(p.time_predict(fr, out, 20) / 20 for _ in range(2)))
+            keep.append((fr, out))
+        p.close()
+    print("ms per 1000-frame batch over six placements:", [round(t, 4) for t in times])
+    assert max(times) / min(times) < 1.06, times

@@ -946,8 +946,11 @@ void Encoder::Finish(Callback callback, void* payload) {
   }
   s.finished = true;
   if (s.failed.load()) {  // no index: the stream ends with the last chunk that was emitted
-    for (Impl::Batch* b : s.emit_q) delete b;
+    for (Impl::Batch* b : s.emit_q) delete b;  // every open batch is in here, `cur` and the queued ones included
     s.emit_q.clear();
+    s.cur = nullptr;
+    for (auto& q : s.gpu_q) q.clear();
+    for (auto& q : s.ready_q) q.clear();
     s.ReleaseContexts();
     return;
   }

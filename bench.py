@@ -314,7 +314,7 @@ def main():
         if len(chunk_ms) >= 400:
             break
     # per-kernel split (events around every launch, separate pass)
-    _, kernel_ms = pred.time_predict(d_frames, out, 5 if args.quick else 20, per_kernel=True)
+    _, kernel_ms = pred.time_predict(d_frames, out, 5 if args.quick else 100, per_kernel=True)   # 100 launches: the split of a handful is noisy (1-2 %)
     names = pred.forward_kernel_names() + ["-"]
     copy_gbps = pkg.copy_bandwidth_GBps(1 << 30, 5, device=local_rank, shape=1) if rank == 0 else 0.0
     copy_chunked_gbps = pkg.copy_bandwidth_GBps(1 << 30, 5, device=local_rank, shape=0) if rank == 0 else 0.0

@@ -305,8 +305,8 @@ static fpvhip_ctx* create_impl(int device, const Geom& g, uint32_t max_batch,
     HIPOK(c, hipMalloc(reinterpret_cast<void**>(&c->d_dhigh), g.npix));
     HIPOK(c, hipMalloc(reinterpret_cast<void**>(&c->d_dlow), g.npix));
     HIPOK(c, hipMalloc(reinterpret_cast<void**>(&c->d_dtmp), (size_t)g.npix * 2));
-    HIPOK(c, hipMalloc(reinterpret_cast<void**>(&c->d_inv_diag), 16));
-    HIPOK(c, hipMemset(c->d_inv_diag, 0, 16));
+    HIPOK(c, hipMalloc(reinterpret_cast<void**>(&c->d_inv_diag), 64));
+    HIPOK(c, hipMemset(c->d_inv_diag, 0, 64));
     if (g.fwd_ok) {
       HIPOK(c, hipMalloc(&c->d_ws, fpvhip::fwd_workspace_bytes(g, max_batch)));
       fpvhip::carve_fwd_workspace(g, max_batch, c->d_ws, &c->ws);
@@ -755,7 +755,15 @@ int fpvhip_inverse_pass_stats(fpvhip_ctx* c, uint32_t* out, int reset) {
   HIPOK(c, hipSetDevice(c->device));
   HIPOK(c, hipDeviceSynchronize());
   HIPOK(c, hipMemcpy(out, c->d_inv_diag, 16, hipMemcpyDeviceToHost));
-  if (reset) HIPOK(c, hipMemset(c->d_inv_diag, 0, 16));
+#ifdef FPV_EXP_WAITS  // experiment build: time at the barriers of the three-wave inverse (see k_inverse_trio)
+  {
+    uint32_t w[16];
+    HIPOK(c, hipMemcpy(w, c->d_inv_diag, 64, hipMemcpyDeviceToHost));
+    fprintf(stderr, "EXP_WAITS chain: at barriers %u of %u; i/o wave 1: at barriers %u of %u (x16 clocks, summed over frames)\n",
+            w[4], w[5], w[8], w[7]);
+  }
+#endif
+  if (reset) HIPOK(c, hipMemset(c->d_inv_diag, 0, 64));
   return 0;
 }
 

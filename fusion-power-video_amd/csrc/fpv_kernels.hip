@@ -1412,6 +1412,39 @@ __device__ __forceinline__ uint32_t inv_px(uint32_t n, uint32_t w, uint32_t d, u
   return as_u32(as_pk((uint32_t)md) + as_pk(r));      // v_pk_add_u16: low lane wraps mod 2^16
 }
 
+// The same three operations spelled out, for the speculative kernels.  The compiler's own choice
+// for the last one is v_pk_add_u16, and it puts an s_nop behind every packed add whose result
+// the next VALU instruction reads (its dst-select forwarding rule): one issue slot in four on
+// the serial path.  v_add_u16 (VOP2) wraps mod 2^16 and writes zeros to the upper half on
+// gfx9-family parts, and no such rule applies to it.
+// Four consecutive chain steps as ONE assembly statement, for the speculative kernels.  Written
+// in C++ the last operation of a step becomes v_pk_add_u16, and the backend puts an s_nop behind
+// every packed add whose result the next VALU instruction reads (its dst-select forwarding
+// rule): one issue slot in four on the serial path.  v_add_u16 (VOP2) wraps mod 2^16 and writes
+// zeros to the upper half on gfx9-family parts, and no such rule applies to it; inside one
+// statement the backend adds nothing (between statements it still does: one s_nop per four
+// pixels instead of one per pixel).
+__device__ __forceinline__ uint32_t inv_px4(const uint32_t* n, uint32_t w, const uint32_t* d, const uint32_t* r, uint32_t* x) {
+#ifdef FPV_INV_PK_ADD
+  x[0] = w = inv_px(n[0], w, d[0], r[0]);
+  x[1] = w = inv_px(n[1], w, d[1], r[1]);
+  x[2] = w = inv_px(n[2], w, d[2], r[2]);
+  x[3] = w = inv_px(n[3], w, d[3], r[3]);
+  return w;
+#else
+  uint32_t x0, x1, x2, x3;
+  asm("v_add_u32_e32 %0, %5, %4\n\tv_med3_i32 %0, %6, %4, %0\n\tv_add_u16_e32 %0, %0, %7\n\t"
+      "v_add_u32_e32 %1, %8, %0\n\tv_med3_i32 %1, %9, %0, %1\n\tv_add_u16_e32 %1, %1, %10\n\t"
+      "v_add_u32_e32 %2, %11, %1\n\tv_med3_i32 %2, %12, %1, %2\n\tv_add_u16_e32 %2, %2, %13\n\t"
+      "v_add_u32_e32 %3, %14, %2\n\tv_med3_i32 %3, %15, %2, %3\n\tv_add_u16_e32 %3, %3, %16"
+      : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3)
+      : "v"(w), "v"(d[0]), "v"(n[0]), "v"(r[0]), "v"(d[1]), "v"(n[1]), "v"(r[1]),
+        "v"(d[2]), "v"(n[2]), "v"(r[2]), "v"(d[3]), "v"(n[3]), "v"(r[3]));
+  x[0] = x0; x[1] = x1; x[2] = x2; x[3] = x3;
+  return x3;
+#endif
+}
+
 __global__ __launch_bounds__(64) void k_inverse_fast(
     const uint8_t* __restrict__ high, const uint8_t* __restrict__ low,
     const uint8_t* __restrict__ dhigh, const uint8_t* __restrict__ dlow,
@@ -1790,7 +1823,7 @@ __global__ __launch_bounds__(64) void k_inverse_spec(
       if (run) {
         uint32_t w = in;
 #pragma unroll
-        for (int k = 0; k < K; k++) X[k] = w = inv_px(N[k], w, D[k], R[k]);
+        for (int k = 0; k < K; k += 4) w = inv_px4(N + k, w, D + k, R + k, X + k);
       }
       npass++;
       uint32_t pred = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)X[K - 1], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
@@ -1812,7 +1845,7 @@ __global__ __launch_bounds__(64) void k_inverse_spec(
         if (run) {
           uint32_t w = in;
 #pragma unroll
-          for (int k = 0; k < K; k++) X[k] = w = inv_px(N[k], w, D[k], R[k]);
+          for (int k = 0; k < K; k += 4) w = inv_px4(N + k, w, D + k, R + k, X + k);
         }
         npass++;
         uint32_t pred = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)X[K - 1], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
@@ -1908,19 +1941,26 @@ __device__ __forceinline__ void dma4(const uint8_t* src, uint8_t* dst_wave_unifo
                                    reinterpret_cast<uint32_t*>(dst_wave_uniform), 4, 0, 0);
 }
 
-template <int K4>
+// SIMDs with a chain wave of k_inverse_trio on them, one word per CU (index: XCC, SE, SH, CU of
+// HW_ID), bits 0..3.  Device-wide on purpose: the claim is about the physical SIMD, whichever
+// context or stream the other frame belongs to.
+constexpr uint32_t kChainSimdWords = 4096;
+__device__ uint32_t g_chain_simd_mask[kChainSimdWords];
+
+template <int K4, int M>
 __global__ __launch_bounds__(192) void k_inverse_trio(
     const uint8_t* __restrict__ high, const uint8_t* __restrict__ low,
     const uint8_t* __restrict__ dhigh, const uint8_t* __restrict__ dlow,
     const uint8_t* __restrict__ flags, uint16_t* __restrict__ frames, Geom g,
-    uint32_t* __restrict__ pass_count) {
+    uint32_t ring_bytes, uint32_t* __restrict__ pass_count) {
   constexpr int K = 4 * K4;
   constexpr uint32_t S = 64u * K;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint8_t* ring = smem;                 // reconstructed high bytes, flat index & m
-  uint8_t* rbuf = smem + g.spec_ring;   // residual bytes of superstep t at rbuf + (t & 3) * S
-  uint8_t* lbuf = rbuf + 4 * S;         // low / delta-high / delta-low bytes of superstep t at lbuf + ((t & 1) * 3 + plane) * S
-  const uint32_t role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  uint8_t* rbuf = smem + ring_bytes;    // residual bytes of superstep t at rbuf + (t & (2 M - 1)) * S
+  uint8_t* lbuf = rbuf + 2 * M * S;     // low / delta-high / delta-low bytes of the q-th superstep of a block at lbuf + (q * 3 + plane) * S
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  uint32_t role = wave;  // 0 chain, 1 and 2 i/o; frames with a chain reassign it below (claim_chain_simd)
   const uint32_t frame = blockIdx.x, lane = threadIdx.x & 63;
   const size_t fbase = (size_t)frame * g.npix;
   const uint8_t* hp = high + fbase;
@@ -1928,14 +1968,21 @@ __global__ __launch_bounds__(192) void k_inverse_trio(
   uint16_t* outp = frames + fbase;
   const uint32_t f = flags[frame];
   const bool use_delta = (f & 1) && dhigh, use_cg = f & 2, no_low = (f & 4) || !lp;
-  const uint32_t xs = g.xs, npix = g.npix, m = g.spec_ring - 1;
+  const uint32_t xs = g.xs, npix = g.npix, m = ring_bytes - 1;
 
   // delta^-1 + recombine (cc:335-344) of 4 pixels; planes that do not exist come as zeros
   auto emit4 = [&](uint32_t i, uint32_t h4, uint32_t l4, uint32_t dh4, uint32_t dl4) {
+#ifdef FPV_EXP_NOADD4  // timing experiment only (wrong pixels): the i/o waves without their byte adds
+    const uint32_t hh = h4 ^ dh4, ll = l4 ^ dl4;
+#else
     const uint32_t hh = add4(h4, dh4), ll = add4(l4, dl4);
+#endif
     uint2 o;
     o.x = __builtin_amdgcn_perm(hh, ll, 0x05010400u);
     o.y = __builtin_amdgcn_perm(hh, ll, 0x07030602u);
+#ifdef FPV_EXP_NOSTORE  // timing experiment only: no pixel stores (except impossible values)
+    if (o.x == 0x12345678u && o.y == 0x9abcdef0u)
+#endif
     *reinterpret_cast<uint2*>(outp + i) = o;
   };
   const uint8_t* lsrc = no_low ? hp : lp;  // readable dummies for planes that do not exist
@@ -1994,31 +2041,70 @@ __global__ __launch_bounds__(192) void k_inverse_trio(
 
   const uint32_t head = min(xs + 4, npix);
   const uint32_t nsteps = (npix - head + S - 1) / S;
+  const uint32_t nblocks = (nsteps + M - 1) / M;  // the waves meet once per block of M supersteps
+
+  // Which of the three waves runs the chain?  The one whose SIMD no other frame's chain wave
+  // is on.  A chain wave issues on three of four issue slots of its SIMD; two of them on one
+  // SIMD take a quarter longer each, and the batch ends with its slowest frame: measured with
+  // the chain always on wave 0 (tools/exp/inv_placement.py, 1000 frames) one CU in 250 gave two
+  // workgroups the same starting SIMD, and those two frames ran 2.02 M clocks where the mean was
+  // 1.62 M and every other frame stayed under 1.74 M -- a seventh of the batch time for one pair.
+  // Per CU a word in device memory holds the SIMDs taken; a workgroup claims a free one among
+  // those its waves are on (returning atomics, once per frame) and gives it back at the end.
+  uint32_t* ctl = reinterpret_cast<uint32_t*>(rbuf + 5 * M * S);  // 8 words behind the plane slots
+  uint32_t claimed_simd = 4, cu_index = 0;
+  {
+    uint32_t hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const uint32_t simd = (hw >> 4) & 3;
+    cu_index = ((xcc & 0xf) << 8 | ((hw >> 8) & 0xff)) & (kChainSimdWords - 1);  // XCC, SE, SH, CU
+    if (lane == 0) ctl[wave] = simd;
+    lds_barrier();
+    if (wave == 0) {
+      uint32_t pick = 0, got = 4;
+      if (lane == 0) {
+#ifndef FPV_NO_CHAIN_CLAIM
+        for (uint32_t c = 0; c < 3 && got == 4; c++) {
+          const uint32_t sd = ctl[c];
+          if (!(atomicOr(&g_chain_simd_mask[cu_index], 1u << sd) & (1u << sd))) { pick = c; got = sd; }
+        }
+#endif
+        ctl[4] = pick;
+        ctl[5] = got;
+      }
+    }
+    lds_barrier();
+    const uint32_t pick = ctl[4];
+    claimed_simd = ctl[5];
+    role = wave == pick ? 0u : wave == (pick + 1) % 3 ? 1u : 2u;
+    role = __builtin_amdgcn_readfirstlane(role);
+  }
+#ifdef FPV_EXP_HWID
+  const uint64_t exp_hw_t0 = clock64();
+#endif
   uint32_t w_prev = 0, npass = 0, maxpass = 0;  // chain wave
+#ifdef FPV_EXP_WAITS  // experiment: where the waves of a frame wait (shader clocks, summed over the frame)
+  uint64_t exp_bar = 0, exp_t0 = clock64();
+#endif
 #ifndef FPV_NO_CHAIN_PRIO
   // The chain wave is the frame's critical path; on its SIMD it competes with i/o waves of
   // other frames.  Issue arbitration goes by priority first, then age (MI355X_MICROARCH.md).
   if (role == 0) __builtin_amdgcn_s_setprio(3);
 #endif
 
-  // i/o waves: stage superstep t's residuals / planes into LDS (coalesced layout:
-  // dword k * 64 + lane).  Indices are clamped into the frame; what lies beyond the
-  // last pixel is never emitted and never anybody's north.
-  auto dma_r = [&](uint32_t t) {
+  // i/o wave 1 owns the k-groups [0, KA) of every superstep (64 lanes x 4 bytes each), i/o
+  // wave 2 the groups [KA, K4): both work in every block, half of it each.  Indices are clamped
+  // into the frame; what lies beyond the last pixel is never emitted and never anybody's north.
+  constexpr int KA = (K4 + 1) / 2;
+  auto dma_r = [&](uint32_t t, auto k0, auto k1) {  // residuals of superstep t -> LDS (dword k * 64 + lane)
 #pragma unroll
-    for (int k = 0; k < K4; k++)
-      dma4(hp + min(head + t * S + (k * 64 + lane) * 4, last4), rbuf + (t & 3) * S + k * 256);
+    for (int k = k0; k < k1; k++)
+      dma4(hp + min(head + t * S + (k * 64 + lane) * 4, last4), rbuf + (t & (2 * M - 1)) * S + k * 256);
   };
-  auto dma_ldh = [&](uint32_t t) {
-    uint8_t* base = lbuf + (t & 1) * 3 * S;
-#pragma unroll
-    for (int k = 0; k < K4; k++) {
-      const uint32_t ic = min(head + t * S + (k * 64 + lane) * 4, last4);
-      dma4(lsrc + ic, base + k * 256);
-      dma4(dhsrc + ic, base + S + k * 256);
-      dma4(dlsrc + ic, base + 2 * S + k * 256);
-    }
-  };
+  using IC0 = std::integral_constant<int, 0>;
+  using ICA = std::integral_constant<int, KA>;
+  using ICK = std::integral_constant<int, K4>;
 
   if (role == 0) {
     // Head: the first xs + 1 pixels are literals (cc:327 starts at xs + 1); pixels
@@ -2041,20 +2127,104 @@ __global__ __launch_bounds__(192) void k_inverse_trio(
             *reinterpret_cast<const uint32_t*>(dhsrc + o) & dmask,
             *reinterpret_cast<const uint32_t*>(dlsrc + o) & dmask);
     w_prev = (uint32_t)ring[(head - 1) & m] << 8;  // wave-uniform: final x[s-1] << 8
-  } else if (role == 1) {  // even supersteps: residuals of 0 and 2, planes of 0
-    dma_r(0);
-    dma_r(2);
-    dma_ldh(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  } else {  // odd supersteps: residuals of 1 (3 and the planes of 1 follow in iteration 0)
-    dma_r(1);
+  } else {  // residuals of block 0
+    auto first = [&](auto k0, auto k1) {
+      for (uint32_t t = 0; t < (uint32_t)M && t < nsteps; t++) dma_r(t, k0, k1);
+    };
+    if (role == 1) first(IC0{}, ICA{});
+    else first(ICA{}, ICK{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   lds_barrier();
 
-  for (uint32_t t = 0; t <= nsteps; t++) {
-    if (role == 0) {
-      if (t < nsteps) {
+  // One phase of an i/o wave, for its own k-groups: the residuals of block b + 1 first (the chain
+  // wave needs them behind the next barrier: they get the whole phase to land), then the output
+  // of block b - 1 (ring + the plane bytes staged a phase ago -> delta^-1 + recombine ->
+  // stores), then the plane bytes of block b into the slots just read -- all loads by LDS-DMA.
+  // vmcnt retires in issue order, so the counted wait in front of the barrier retires the
+  // residual loads and the stores and leaves the plane loads, issued last, in flight: they are
+  // used a whole phase later, behind the wait at the top.
+  // The LDS reads of the output are inline assembly: in front of a compiler-visible LDS access
+  // that follows LDS-DMA the backend inserts s_waitcnt vmcnt(0) (the DMA might write the same
+  // bytes), which would drain the residual loads just issued.  Every value is named by the wait
+  // statement behind which it exists, so no use can move in front of it.
+  const uint32_t ring_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(ring));
+  const uint32_t lbuf_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lbuf));
+  auto peek = [&](uint32_t lds_addr) {
+    uint32_t v;
+    asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(lds_addr) : "memory");
+    return v;
+  };
+  auto io_phase = [&](uint32_t b, auto k0, auto k1) {
+    constexpr int NK = decltype(k1)::value - decltype(k0)::value;
+    if constexpr (NK > 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the planes of block b - 1 have landed
+#pragma unroll
+      for (int q = 0; q < M; q++) {
+        const uint32_t t = (b + 1) * M + q;
+        if (t < nsteps) dma_r(t, k0, k1);
+      }
+      bool all = true;
+#pragma unroll
+      for (int q = 0; q < M; q++) {
+        const uint32_t t = (b - 1) * M + q;
+        if (b >= 1 && t < nsteps) {
+          const uint32_t s0 = head + t * S;
+          const uint32_t base = lbuf_lds + q * 3 * S;
+          const bool full = s0 + S <= npix;  // every superstep but the last one
+          uint32_t h4[NK], l4[NK], dh4[NK], dl4[NK];
+#pragma unroll
+          for (int k = 0; k < NK; k++) {
+            const uint32_t o = ((k0 + k) * 64 + lane) * 4;
+            h4[k] = peek(ring_lds + ((s0 + o) & m));
+            l4[k] = peek(base + o);
+            dh4[k] = peek(base + S + o);
+            dl4[k] = peek(base + 2 * S + o);
+          }
+#pragma unroll
+          for (int k = 0; k < NK; k++)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h4[k]), "+v"(l4[k]), "+v"(dh4[k]), "+v"(dl4[k])::"memory");
+#pragma unroll
+          for (int k = 0; k < NK; k++) {
+            const uint32_t px = s0 + ((k0 + k) * 64 + lane) * 4;
+            if (full || px < npix) emit4(px, h4[k], l4[k] & lmask, dh4[k] & dmask, dl4[k] & dmask);
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < M; q++) {  // (the reads above have returned: the plane slots may be refilled)
+        const uint32_t t = b * M + q;
+        if (t < nsteps) {
+          uint8_t* base = lbuf + q * 3 * S;
+#pragma unroll
+          for (int k = k0; k < k1; k++) {
+            const uint32_t ic = min(head + t * S + (k * 64 + lane) * 4, last4);
+            dma4(lsrc + ic, base + k * 256);
+            dma4(dhsrc + ic, base + S + k * 256);
+            dma4(dlsrc + ic, base + 2 * S + k * 256);
+          }
+        } else {
+          all = false;
+        }
+      }
+      if (all) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * M * NK) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  };
+  // Each role runs its own loop over the blocks; every wave passes the same nblocks + 1 barriers.
+  auto sync = [&] {
+#ifdef FPV_EXP_WAITS
+    const uint64_t exp_b = clock64();
+#endif
+    lds_barrier();
+#ifdef FPV_EXP_WAITS
+    exp_bar += clock64() - exp_b;
+#endif
+  };
+  if (role == 0) {
+    for (uint32_t b = 0; b <= nblocks; b++) {
+#pragma unroll 1
+      for (uint32_t t = b * M; t < (b + 1) * M && t < nsteps; t++) {
         const uint32_t s0 = head + t * S, start = s0 + lane * K;
         const bool active = start < npix;
         uint32_t N[K], D[K], R[K], X[K];
@@ -2065,7 +2235,7 @@ __global__ __launch_bounds__(192) void k_inverse_trio(
 #pragma unroll
           for (int q = 0; q <= K4; q++) nd[q] = *reinterpret_cast<const uint32_t*>(ring + ((nb + 4 * q) & m));
 #pragma unroll
-          for (int q = 0; q < K4; q++) rq[q] = *reinterpret_cast<const uint32_t*>(rbuf + (t & 3) * S + lane * K + 4 * q);
+          for (int q = 0; q < K4; q++) rq[q] = *reinterpret_cast<const uint32_t*>(rbuf + (t & (2 * M - 1)) * S + lane * K + 4 * q);
           uint32_t prev = __builtin_amdgcn_perm(0, nd[0], 0x0c0c030cu);
           guess = prev;  // x[start - 1 - xs] << 8
 #pragma unroll
@@ -2089,12 +2259,15 @@ __global__ __launch_bounds__(192) void k_inverse_trio(
           if (run) {
             uint32_t w = in;
 #pragma unroll
-            for (int k = 0; k < K; k++) X[k] = w = inv_px(N[k], w, D[k], R[k]);
+            for (int k = 0; k < K; k += 4) w = inv_px4(N + k, w, D + k, R + k, X + k);
           }
           npass++;
           uint32_t pred = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)X[K - 1], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
           if (lane == 0) pred = w_prev;
           run = active && pred != in;
+#ifdef FPV_EXP_ONEPASS  // timing experiment only (wrong pixels): how much of the time is the passes?
+          settled = true; break;
+#endif
           if (!__builtin_amdgcn_ballot_w64(run)) { settled = true; break; }
           in = pred;
         }
@@ -2109,7 +2282,7 @@ __global__ __launch_bounds__(192) void k_inverse_trio(
             if (run) {
               uint32_t w = in;
 #pragma unroll
-              for (int k = 0; k < K; k++) X[k] = w = inv_px(N[k], w, D[k], R[k]);
+              for (int k = 0; k < K; k += 4) w = inv_px4(N + k, w, D + k, R + k, X + k);
             }
             npass++;
             uint32_t pred = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)X[K - 1], 0x138, 0xf, 0xf, false);
@@ -2143,39 +2316,43 @@ __global__ __launch_bounds__(192) void k_inverse_trio(
           *reinterpret_cast<uint32_t*>(ring + ((start + 4 * q) & m)) = o;
         }
       }
-    } else if (((t + 1) & 1u) == role - 1) {  // i/o wave of the parity of superstep t - 1 (and t + 1, t + 3)
-      // everything this wave issued two iterations ago has landed: planes of t - 1, residuals of t + 1
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (t >= 1) {  // output phase of superstep t - 1
-        const uint32_t s0 = head + (t - 1) * S;
-        const uint8_t* base = lbuf + ((t - 1) & 1) * 3 * S;
-        uint32_t h4[K4], l4[K4], dh4[K4], dl4[K4];
-#pragma unroll
-        for (int k = 0; k < K4; k++) {
-          const uint32_t o = (k * 64 + lane) * 4;
-          h4[k] = *reinterpret_cast<const uint32_t*>(ring + ((s0 + o) & m));
-          l4[k] = *reinterpret_cast<const uint32_t*>(base + o) & lmask;
-          dh4[k] = *reinterpret_cast<const uint32_t*>(base + S + o) & dmask;
-          dl4[k] = *reinterpret_cast<const uint32_t*>(base + 2 * S + o) & dmask;
-        }
-#pragma unroll
-        for (int k = 0; k < K4; k++) {
-          const uint32_t i = s0 + (k * 64 + lane) * 4;
-          if (i < npix) emit4(i, h4[k], l4[k], dh4[k], dl4[k]);
-        }
-        wave_lds_sync();  // the reads above are done before the next planes overwrite the buffer
-      }
-      if (t + 1 < nsteps) dma_ldh(t + 1);
-      if (t + 3 < nsteps) dma_r(t + 3);
+      sync();
     }
-    lds_barrier();
+  } else if (role == 1) {
+    for (uint32_t b = 0; b <= nblocks; b++) {
+      io_phase(b, IC0{}, ICA{});
+      sync();
+    }
+  } else {
+    for (uint32_t b = 0; b <= nblocks; b++) {
+      io_phase(b, ICA{}, ICK{});
+      sync();
+    }
   }
+  if (role == 0 && lane == 0 && claimed_simd < 4) atomicAnd(&g_chain_simd_mask[cu_index], ~(1u << claimed_simd));
+#ifdef FPV_EXP_WAITS
+  if (pass_count && lane == 0) {
+    const uint32_t tot = (uint32_t)((clock64() - exp_t0) >> 4);
+    if (role == 0) { atomicAdd(&pass_count[4], (uint32_t)(exp_bar >> 4)); atomicAdd(&pass_count[5], tot); }
+    if (role == 1) { atomicAdd(&pass_count[8], (uint32_t)(exp_bar >> 4)); atomicAdd(&pass_count[7], tot); }
+  }
+#endif
   if (pass_count && role == 0 && lane == 0) {  // diagnostics: supersteps and passes (bench / tests)
     atomicAdd(&pass_count[0], nsteps);
     atomicAdd(&pass_count[1], npass);
     atomicMax(&pass_count[2], npass);
     atomicMax(&pass_count[3], maxpass);
   }
+#ifdef FPV_EXP_HWID  // experiment (destroys the first four pixels): where the chain wave ran and for how long
+  if (role == 0 && lane == 0) {
+    uint32_t hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    uint32_t* o = reinterpret_cast<uint32_t*>(outp);
+    o[0] = (xcc & 0xf) << 16 | (hw & 0xffff);
+    o[1] = (uint32_t)((clock64() - exp_hw_t0) >> 4);
+  }
+#endif
 }
 
 }  // namespace
@@ -2536,6 +2713,7 @@ static hipError_t predict_impl(const Geom& g, const uint16_t* d_frames,
                                hipStream_t s, hipEvent_t* ev) {
   const int with_delta = d_dhigh != nullptr;
   if (g.tile_ok && ws.trec) {  // dispatch-ordered tiles (fpv_tile.inc)
+    if ((uint64_t)nframes * g.tile_tiles > 0x7fffffffull) return hipErrorInvalidValue;  // one workgroup per tile
     TileLaunch L;
     TileArgs& a = L.g;
     a.xs = g.xs; a.ys = g.ys; a.npix = g.npix; a.pw = g.pw; a.npv = g.npv;
@@ -2643,58 +2821,90 @@ hipError_t launch_predict(const Geom& g, const uint16_t* d_frames,
                              d_low, d_preview, d_flags, s, ev);
 }
 
-// Frames whose three-wave workgroups (k_inverse_trio) are all resident at the same time on
-// the current device: workgroups per CU as the runtime's occupancy query sees them (register
-// and LDS budget of the instantiation for this geometry) times the CUs.  Cached per device / K4.
-static uint32_t trio_capacity(const Geom& g, uint32_t k4) {
+// k_inverse_trio<K4, M>: supersteps per barrier (the waves of a frame meet once per block of M
+// supersteps), ring and LDS bytes.  The ring holds the block being written, the block being
+// emitted and the row above the first superstep of either.
+static uint32_t trio_block_max() {  // FPV_TRIO_BLOCK caps it; read per launch: A/B runs switch it inside one process
+  const char* e = getenv("FPV_TRIO_BLOCK");
+  const int v = e ? atoi(e) : 4;
+  return v >= 4 ? 4u : v >= 2 ? 2u : 1u;
+}
+static uint32_t trio_ring(const Geom& g, uint32_t k4, uint32_t mblk) {
+  const uint32_t S = 256 * k4;
+  uint32_t r = 1;
+  while (r < 2 * mblk * S + g.xs + 16) r <<= 1;
+  return r;
+}
+static size_t trio_lds(const Geom& g, uint32_t k4, uint32_t mblk) {  // ring, 2 M residual + 3 M plane slots, control words
+  return trio_ring(g, k4, mblk) + 5 * mblk * 256 * k4 + 64;
+}
+
+// Frames whose three-wave workgroups (k_inverse_trio<k4, mblk>) are all resident at the same
+// time on the current device: the runtime's occupancy answer for the instantiation times the CUs.
+static uint32_t trio_capacity(const Geom& g, uint32_t k4, uint32_t mblk) {
   static std::mutex m;
-  static uint32_t cap[64][kSpecMaxK4 + 1] = {};
+  static uint32_t capm[64][kSpecMaxK4 + 1][5] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) dev = 0;
   dev &= 63;
-  if (k4 == 0 || k4 > kSpecMaxK4) return 0;
+  if (k4 == 0 || k4 > kSpecMaxK4 || (mblk != 1 && mblk != 2 && mblk != 4)) return 0;
+  if (trio_lds(g, k4, mblk) > 64 * 1024) return 0;
   std::lock_guard<std::mutex> l(m);
-  if (!cap[dev][k4]) {
+  uint32_t* cap_slot = &capm[dev][k4][mblk];
+  if (!*cap_slot) {
     int blocks = 0;
-    const size_t lds = g.spec_ring + 10 * 256 * k4;
+    const size_t lds = trio_lds(g, k4, mblk);
     hipError_t e = hipErrorInvalidValue;
-    switch (k4) {
-#define FPV_OCC(K4) case K4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_inverse_trio<K4>, 192, lds); break;
-      FPV_OCC(1) FPV_OCC(2) FPV_OCC(3) FPV_OCC(4) FPV_OCC(5) FPV_OCC(6)
+#define FPV_OCC(K4, MB) if (k4 == K4 && mblk == MB) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_inverse_trio<K4, MB>, 192, lds);
+#define FPV_OCC3(K4) FPV_OCC(K4, 1) FPV_OCC(K4, 2) FPV_OCC(K4, 4)
+    FPV_OCC3(1) FPV_OCC3(2) FPV_OCC3(3) FPV_OCC3(4) FPV_OCC3(5) FPV_OCC3(6)
+#undef FPV_OCC3
 #undef FPV_OCC
-    }
     if (e != hipSuccess || blocks <= 0) blocks = 3;
-    cap[dev][k4] = (uint32_t)blocks * device_cus();
+    *cap_slot = (uint32_t)blocks * device_cus();
   }
-  return cap[dev][k4];
+  return *cap_slot;
 }
 
 // Which inverse kernel a batch of nframes takes: 3 three waves per frame, 0 one wave per
 // frame (speculative), 1 the serial-chain kernel, 2 the byte-granular one; *k4 = the segment
-// length (dwords per lane and superstep) the speculative kernels run with.
-// Three waves per frame as long as EVERY frame's workgroup is resident at the same time: at the
-// geometry's own k4 (1024 frames at 1280x800 on MI355X) or, for batches just beyond that, at
-// k4 - 1 (shorter supersteps, fewer registers: five workgroups per CU instead of four, 1280
-// frames; 1100 frames 1.18 ms against 1.36 with one wave per frame, profiles/r03_inverse_sizes.log).
-static int inverse_mode(const Geom& g, uint32_t nframes, uint32_t* k4) {
+// length (dwords per lane and superstep) the speculative kernels run with, *mblk = supersteps
+// per barrier of the three-wave kernel.
+// Three waves per frame as long as EVERY frame's workgroup is resident at the same time.  In
+// order of preference (1280x800 on MI355X; profiles/r03_inverse_sizes.log, r03_inverse_ab.log):
+//   blocks of 4 supersteps at the geometry's own k4 = 5   41 KB of LDS, 3 workgroups per CU:   768 frames
+//   blocks of 4 at k4 - 1 (shorter supersteps)            37 KB, 4 per CU:                    1024 frames
+//   blocks of 2 at k4                                     21 KB, 4 per CU (registers):        1024 frames
+//   blocks of 2 at k4 - 1 (fewer registers)               5 per CU:                           1280 frames
+// (1000 frames: 0.787 ms with blocks of 4 at k4 - 1, 0.803 with blocks of 2 at k4, same run)
+// and one wave per frame beyond (a second round of workgroups would run nearly alone).
+static int inverse_mode(const Geom& g, uint32_t nframes, uint32_t* k4, uint32_t* mblk) {
   int mode = -1;  // the environment is read per launch: tests switch kernels inside one process
   *k4 = g.spec_k4;
+  *mblk = 1;
   if (getenv("FPV_INVERSE_SLOW")) {
     mode = 2;
   } else if (const char* e = getenv("FPV_INVERSE")) {
     mode = e[0] == 'f' ? 1 : e[0] == 's' && e[1] == 'l' ? 2 : e[0] == 's' ? 0 : e[0] == 't' ? 3 : -1;
   }
-  if (mode < 0) {
+  if (mode < 0 || mode == 3) {
+    const bool forced = mode == 3;
+    const uint32_t mmax = trio_block_max();
     mode = 0;
-    if (g.spec_k4 && nframes <= trio_capacity(g, g.spec_k4)) mode = 3;
-    else if (g.spec_k4 > 1 && nframes <= trio_capacity(g, g.spec_k4 - 1)) { mode = 3; *k4 = g.spec_k4 - 1; }
+    for (uint32_t mb = mmax; mb >= 1 && mode == 0; mb >>= 1)
+      for (uint32_t kk = g.spec_k4; kk + 1 >= g.spec_k4 && kk >= 1 && mode == 0; kk--)
+        if (nframes <= trio_capacity(g, kk, mb)) { mode = 3; *k4 = kk; *mblk = mb; }
+    if (mode == 0 && forced && g.spec_k4) {  // FPV_INVERSE=trio beyond the capacity: the longest block that fits
+      for (uint32_t mb = mmax; mb >= 1 && mode == 0; mb >>= 1)
+        if (trio_capacity(g, g.spec_k4, mb)) { mode = 3; *mblk = mb; }
+    }
   }
   return mode;
 }
 
 const char* inverse_kernel_name(const Geom& g, uint32_t nframes) {
-  uint32_t k4;
-  const int mode = inverse_mode(g, nframes, &k4);
+  uint32_t k4, mblk;
+  const int mode = inverse_mode(g, nframes, &k4, &mblk);
   const bool aligned = (g.xs & 3) == 0 && (g.npix & 3) == 0;
   if (mode == 3 && g.spec_k4) return "k_inverse_trio";
   if (mode == 0 && g.spec_k4) return "k_inverse_spec";
@@ -2715,20 +2925,19 @@ hipError_t launch_inverse(const Geom& g, const uint8_t* d_high,
   // four such workgroups per CU); beyond that a second round of workgroups would run nearly
   // alone, and one wave per frame (more frames resident, less synchronisation) wins:
   // 1100 frames 1.35 ms against 1.56, 2000 frames 1.65 against 2.28 (profiles/r02_inverse_ab.log).
-  uint32_t k4;
-  const int mode = inverse_mode(g, nframes, &k4);
+  uint32_t k4, mblk;
+  const int mode = inverse_mode(g, nframes, &k4, &mblk);
   const bool aligned = (g.xs & 3) == 0 && (g.npix & 3) == 0;
   if (mode == 3 && g.spec_k4) {
-#define FPV_LAUNCH_TRIO(K4)                                                                     \
-  case K4:                                                                                      \
-    k_inverse_trio<K4><<<nframes, 192, g.spec_ring + 10 * 256 * K4, s>>>(                       \
-        d_high, d_low, d_dhigh, d_dlow, d_flags, d_frames, g, d_diag);                          \
-    break;
-    switch (k4) {
-      FPV_LAUNCH_TRIO(1) FPV_LAUNCH_TRIO(2) FPV_LAUNCH_TRIO(3)
-      FPV_LAUNCH_TRIO(4) FPV_LAUNCH_TRIO(5) FPV_LAUNCH_TRIO(6)
-      default: return hipErrorInvalidValue;
-    }
+#define FPV_LAUNCH_TRIO(K4, MB)                                                                       \
+  if (k4 == K4 && mblk == MB)                                                                         \
+    k_inverse_trio<K4, MB><<<nframes, 192, trio_lds(g, K4, MB), s>>>(                                 \
+        d_high, d_low, d_dhigh, d_dlow, d_flags, d_frames, g, trio_ring(g, K4, MB), d_diag);
+#define FPV_LAUNCH_TRIO3(K4) FPV_LAUNCH_TRIO(K4, 1) FPV_LAUNCH_TRIO(K4, 2) FPV_LAUNCH_TRIO(K4, 4)
+    if (k4 < 1 || k4 > kSpecMaxK4) return hipErrorInvalidValue;
+    FPV_LAUNCH_TRIO3(1) FPV_LAUNCH_TRIO3(2) FPV_LAUNCH_TRIO3(3)
+    FPV_LAUNCH_TRIO3(4) FPV_LAUNCH_TRIO3(5) FPV_LAUNCH_TRIO3(6)
+#undef FPV_LAUNCH_TRIO3
 #undef FPV_LAUNCH_TRIO
   } else if (mode == 0 && g.spec_k4) {
 #define FPV_LAUNCH_SPEC(K4)                                                                  \

@@ -56,5 +56,5 @@ for spec, p, times, ok, st, env in preds:
     t = np.array(times); med = float(np.median(t)); ref = ref or med
     print(json.dumps({"lib": os.path.basename(spec), "frames": N, "ms_min": round(float(t.min()), 4), "ms_median": round(med, 4),
                       "vs_first": round(med / ref, 4), "frames_per_s": round(N / med * 1e3), "bit_exact": ok,
-                      "passes_per_superstep": round(st[1] / max(st[0], 1), 3),
+                      "passes_per_superstep": round(st[1] / max(st[0], 1), 3), "extremes": list(p.last_pass_extremes),
                       "frac_of_8TBps": round(N * 4 * NP / (med / 1e3) / 8e12, 4)}), flush=True)

@@ -1956,7 +1956,7 @@ __global__ __launch_bounds__(192) void k_inverse_trio(
   constexpr int K = 4 * K4;
   constexpr uint32_t S = 64u * K;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  uint8_t* ring = smem;                 // reconstructed high bytes, flat index & m
+  uint8_t* ring = smem;                 // reconstructed high bytes: pixel i at rix(i) = (i - 4) & m
   uint8_t* rbuf = smem + ring_bytes;    // residual bytes of superstep t at rbuf + (t & (2 M - 1)) * S
   uint8_t* lbuf = rbuf + 2 * M * S;     // low / delta-high / delta-low bytes of the q-th superstep of a block at lbuf + (q * 3 + plane) * S
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1969,6 +1969,7 @@ __global__ __launch_bounds__(192) void k_inverse_trio(
   const uint32_t f = flags[frame];
   const bool use_delta = (f & 1) && dhigh, use_cg = f & 2, no_low = (f & 4) || !lp;
   const uint32_t xs = g.xs, npix = g.npix, m = ring_bytes - 1;
+  auto rix = [&](uint32_t i) { return (i - 4u) & m; };  // ring offset of pixel i (see the chain wave's 128-bit accesses)
 
   // delta^-1 + recombine (cc:335-344) of 4 pixels; planes that do not exist come as zeros
   auto emit4 = [&](uint32_t i, uint32_t h4, uint32_t l4, uint32_t dh4, uint32_t dl4) {
@@ -2110,23 +2111,23 @@ __global__ __launch_bounds__(192) void k_inverse_trio(
     // Head: the first xs + 1 pixels are literals (cc:327 starts at xs + 1); pixels
     // xs+1 .. xs+3 are walked serially so that the supersteps start 4-aligned.
     for (uint32_t o = lane * 4; o < head; o += 256)
-      *reinterpret_cast<uint32_t*>(ring + (o & m)) = *reinterpret_cast<const uint32_t*>(hp + o);
+      *reinterpret_cast<uint32_t*>(ring + rix(o)) = *reinterpret_cast<const uint32_t*>(hp + o);
     wave_lds_sync();
     {
-      int w = ring[xs & m];
+      int w = ring[rix(xs)];
       for (uint32_t i = xs + 1; i < head; i++) {
-        const int x = (ring[i & m] + cg_pred(ring[(i - xs) & m], w, ring[(i - xs - 1) & m])) & 0xff;
-        ring[i & m] = (uint8_t)x;  // every lane writes the same value
+        const int x = (ring[rix(i)] + cg_pred(ring[rix(i - xs)], w, ring[rix(i - xs - 1)])) & 0xff;
+        ring[rix(i)] = (uint8_t)x;  // every lane writes the same value
         w = x;
       }
     }
     wave_lds_sync();
     for (uint32_t o = lane * 4; o < head; o += 256)
-      emit4(o, *reinterpret_cast<const uint32_t*>(ring + (o & m)),
+      emit4(o, *reinterpret_cast<const uint32_t*>(ring + rix(o)),
             *reinterpret_cast<const uint32_t*>(lsrc + o) & lmask,
             *reinterpret_cast<const uint32_t*>(dhsrc + o) & dmask,
             *reinterpret_cast<const uint32_t*>(dlsrc + o) & dmask);
-    w_prev = (uint32_t)ring[(head - 1) & m] << 8;  // wave-uniform: final x[s-1] << 8
+    w_prev = (uint32_t)ring[rix(head - 1)] << 8;  // wave-uniform: final x[s-1] << 8
   } else {  // residuals of block 0
     auto first = [&](auto k0, auto k1) {
       for (uint32_t t = 0; t < (uint32_t)M && t < nsteps; t++) dma_r(t, k0, k1);
@@ -2176,7 +2177,7 @@ __global__ __launch_bounds__(192) void k_inverse_trio(
 #pragma unroll
           for (int k = 0; k < NK; k++) {
             const uint32_t o = ((k0 + k) * 64 + lane) * 4;
-            h4[k] = peek(ring_lds + ((s0 + o) & m));
+            h4[k] = peek(ring_lds + rix(s0 + o));
             l4[k] = peek(base + o);
             dh4[k] = peek(base + S + o);
             dl4[k] = peek(base + 2 * S + o);
@@ -2232,10 +2233,21 @@ __global__ __launch_bounds__(192) void k_inverse_trio(
         {
           const uint32_t nb = start - xs - 4;  // dword holding the north-west of the first pixel
           uint32_t nd[K4 + 1], rq[K4];
+          if constexpr (K4 == 4) {
+            // 16 bytes per lane: dword accesses at a lane stride of 16 bytes are four-way bank conflicts
+            // (odd K4: conflict-free), one 128-bit access per lane is not.  The ring is laid out so
+            // that a lane's four north dwords, and (xs % 16 == 0) the four it writes, are aligned.
+            nd[0] = *reinterpret_cast<const uint32_t*>(ring + rix(nb));
+            const uint4 a = *reinterpret_cast<const uint4*>(ring + rix(nb + 4));  // rix(nb + 4) = (t * S + lane * 16) & m
+            nd[1] = a.x; nd[2] = a.y; nd[3] = a.z; nd[4] = a.w;
+            const uint4 r = *reinterpret_cast<const uint4*>(rbuf + (t & (2 * M - 1)) * S + lane * 16);
+            rq[0] = r.x; rq[1] = r.y; rq[2] = r.z; rq[3] = r.w;
+          } else {
 #pragma unroll
-          for (int q = 0; q <= K4; q++) nd[q] = *reinterpret_cast<const uint32_t*>(ring + ((nb + 4 * q) & m));
+            for (int q = 0; q <= K4; q++) nd[q] = *reinterpret_cast<const uint32_t*>(ring + rix(nb + 4 * q));
 #pragma unroll
-          for (int q = 0; q < K4; q++) rq[q] = *reinterpret_cast<const uint32_t*>(rbuf + (t & (2 * M - 1)) * S + lane * K + 4 * q);
+            for (int q = 0; q < K4; q++) rq[q] = *reinterpret_cast<const uint32_t*>(rbuf + (t & (2 * M - 1)) * S + lane * K + 4 * q);
+          }
           uint32_t prev = __builtin_amdgcn_perm(0, nd[0], 0x0c0c030cu);
           guess = prev;  // x[start - 1 - xs] << 8
 #pragma unroll
@@ -2309,11 +2321,16 @@ __global__ __launch_bounds__(192) void k_inverse_trio(
         }
         maxpass = max(maxpass, npass - npass0);
         w_prev = (uint32_t)__builtin_amdgcn_readlane((int)X[K - 1], 63);
+        uint32_t packed[K4];
 #pragma unroll
-        for (int q = 0; q < K4; q++) {
-          const uint32_t o = __builtin_amdgcn_perm(X[4 * q + 1], X[4 * q], 0x0c0c0501u) |
-                             __builtin_amdgcn_perm(X[4 * q + 3], X[4 * q + 2], 0x05010c0cu);
-          *reinterpret_cast<uint32_t*>(ring + ((start + 4 * q) & m)) = o;
+        for (int q = 0; q < K4; q++)
+          packed[q] = __builtin_amdgcn_perm(X[4 * q + 1], X[4 * q], 0x0c0c0501u) |
+                      __builtin_amdgcn_perm(X[4 * q + 3], X[4 * q + 2], 0x05010c0cu);
+        if (K4 == 4 && (xs & 15) == 0) {  // rix(start) = (xs + t * S + lane * 16) & m: 16-byte aligned
+          *reinterpret_cast<uint4*>(ring + rix(start)) = make_uint4(packed[0], packed[1], packed[2], packed[K4 - 1]);
+        } else {
+#pragma unroll
+          for (int q = 0; q < K4; q++) *reinterpret_cast<uint32_t*>(ring + rix(start + 4 * q)) = packed[q];
         }
       }
       sync();

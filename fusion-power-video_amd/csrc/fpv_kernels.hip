@@ -1914,26 +1914,28 @@ __global__ __launch_bounds__(64) void k_inverse_spec(
 }
 
 
-// k_inverse_trio: the speculative segmented inverse (see k_inverse_spec) with the
+// k_inverse_trio<K4, M>: the speculative segmented inverse (see k_inverse_spec) with the
 // work of a frame split over THREE waves of one workgroup, by role:
 //
-//   wave 0 (chain)  north bytes + residuals from LDS -> operands -> passes ->
-//                   reconstructed bytes into the LDS ring.  Issues no global
-//                   memory instruction inside the superstep loop: its instruction
-//                   stream is the frame's critical path and nothing else.
-//   wave 1, wave 2  (i/o, even / odd supersteps) move every byte the frame needs
-//                   from HBM straight into LDS (global_load_lds: no registers, so
-//                   nothing of a load has to be touched before it is used), two to
-//                   three supersteps ahead: residuals for the chain wave, low plane
-//                   and delta planes for themselves; and they run the output phase of
-//                   the superstep the chain wave finished in the previous iteration:
-//                   ring + staged planes -> delta^-1 + recombine -> coalesced stores.
+//   chain wave      north bytes + residuals from LDS -> operands -> passes ->
+//                   reconstructed bytes into the LDS ring.  Issues no global memory
+//                   instruction inside its loop: its instruction stream is the frame's
+//                   critical path and nothing else.  Which of the three waves it is, the
+//                   workgroup decides at run time: the one on a SIMD that no other
+//                   frame's chain wave is on (g_chain_simd_mask).
+//   two i/o waves   move every byte the frame needs from HBM straight into LDS
+//                   (global_load_lds: no registers, so nothing of a load has to be touched
+//                   before it is used): residuals for the chain wave, low plane and delta
+//                   planes for themselves; and run the output phase: ring + staged planes
+//                   -> delta^-1 + recombine -> coalesced stores.  Each owns half of the
+//                   64-lane x 4-byte groups of every superstep.
 //
-// One workgroup barrier per superstep hands ring(t) to the i/o waves and the
-// residuals of t+1 to the chain wave.  The barrier is a bare s_barrier behind an
-// LDS-only wait, so the i/o waves' loads stay in flight across it; an i/o wave
-// waits for its own loads (vmcnt) only when it is active again, two iterations
-// after issuing them.
+// The waves meet once per BLOCK of M supersteps (one workgroup barrier, a bare s_barrier
+// behind an LDS-only wait, so loads stay in flight across it): in phase b the chain wave runs
+// block b back to back; an i/o wave issues the residual loads of block b + 1, emits block
+// b - 1, issues the plane loads of block b into the slots it has just read, and retires
+// everything but those plane loads with a counted vmcnt before the barrier.  DESIGN.md section
+// 4 has the measurements behind each of these choices.
 
 // 64 lanes x 4 bytes from per-lane global addresses into LDS at dst + 4 * lane.
 __device__ __forceinline__ void dma4(const uint8_t* src, uint8_t* dst_wave_uniform) {

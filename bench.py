@@ -362,6 +362,16 @@ def main():
                "algorithmic_bytes_per_launch": inv_bytes,
                "passes_per_superstep": round(st[1] / max(st[0], 1), 3),
                "roundtrip_bit_exact": exact}
+        if not args.quick:
+            # the same kernel family at smaller batches (the first frames of the same planes): below ~768
+            # frames of this size the chain alone bounds it, and the block length is longer
+            sub = {}
+            for m in (256, 512, 768):
+                if m < n:
+                    it2 = 60
+                    ms2 = pred.time_inverse(out[0][:m], out[1][:m], out[3][:m], rec[:m], it2) / it2
+                    sub[str(m)] = {"ms_per_batch": round(ms2, 4), "frac": round(m * 4 * NPIX / ms2 / 1e6 / HBM_PEAK_GBPS, 4)}
+            inv["smaller_batches"] = sub
         del rec
 
     # Adversarial forward workload (secondary figure): config-0 style noise at the full frame

@@ -2149,15 +2149,10 @@ __global__ __launch_bounds__(192) void k_inverse_trio(
   // used a whole phase later, behind the wait at the top.
   // The LDS reads of the output are inline assembly: in front of a compiler-visible LDS access
   // that follows LDS-DMA the backend inserts s_waitcnt vmcnt(0) (the DMA might write the same
-  // bytes), which would drain the residual loads just issued.  Every value is named by the wait
-  // statement behind which it exists, so no use can move in front of it.
+  // bytes), which would drain the residual loads just issued.  The reads of a superstep and
+  // their wait are ONE statement, so no value exists outside it before it has landed.
   const uint32_t ring_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(ring));
   const uint32_t lbuf_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lbuf));
-  auto peek = [&](uint32_t lds_addr) {
-    uint32_t v;
-    asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(lds_addr) : "memory");
-    return v;
-  };
   auto io_phase = [&](uint32_t b, auto k0, auto k1) {
     constexpr int NK = decltype(k1)::value - decltype(k0)::value;
     if constexpr (NK > 0) {
@@ -2175,18 +2170,34 @@ __global__ __launch_bounds__(192) void k_inverse_trio(
           const uint32_t s0 = head + t * S;
           const uint32_t base = lbuf_lds + q * 3 * S;
           const bool full = s0 + S <= npix;  // every superstep but the last one
-          uint32_t h4[NK], l4[NK], dh4[NK], dl4[NK];
+          uint32_t h4[NK], l4[NK], dh4[NK], dl4[NK], ra[NK], pa[NK];
 #pragma unroll
           for (int k = 0; k < NK; k++) {
             const uint32_t o = ((k0 + k) * 64 + lane) * 4;
-            h4[k] = peek(ring_lds + rix(s0 + o));
-            l4[k] = peek(base + o);
-            dh4[k] = peek(base + S + o);
-            dl4[k] = peek(base + 2 * S + o);
+            ra[k] = ring_lds + rix(s0 + o);
+            pa[k] = base + o;
           }
-#pragma unroll
-          for (int k = 0; k < NK; k++)
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h4[k]), "+v"(l4[k]), "+v"(dh4[k]), "+v"(dl4[k])::"memory");
+          // reads and their wait in ONE statement: no value exists outside it before it has landed
+#define FPV_RD4(H, L, DH, DL, RA, PA) \
+  "ds_read_b32 " H ", " RA "\n\tds_read_b32 " L ", " PA "\n\tds_read_b32 " DH ", " PA " offset:%c[s1]\n\tds_read_b32 " DL ", " PA " offset:%c[s2]\n\t"
+          static_assert(2 * S < 65536, "plane offsets are DS immediates");
+          if constexpr (NK == 1) {
+            asm volatile(FPV_RD4("%0", "%1", "%2", "%3", "%4", "%5") "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(h4[0]), "=&v"(l4[0]), "=&v"(dh4[0]), "=&v"(dl4[0])
+                         : "v"(ra[0]), "v"(pa[0]), [s1] "n"(S), [s2] "n"(2 * S) : "memory");
+          } else if constexpr (NK == 2) {
+            asm volatile(FPV_RD4("%0", "%1", "%2", "%3", "%8", "%9") FPV_RD4("%4", "%5", "%6", "%7", "%10", "%11") "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(h4[0]), "=&v"(l4[0]), "=&v"(dh4[0]), "=&v"(dl4[0]), "=&v"(h4[1]), "=&v"(l4[1]), "=&v"(dh4[1]), "=&v"(dl4[1])
+                         : "v"(ra[0]), "v"(pa[0]), "v"(ra[1]), "v"(pa[1]), [s1] "n"(S), [s2] "n"(2 * S) : "memory");
+          } else {
+            static_assert(NK == 3, "an i/o wave owns one to three k-groups");
+            asm volatile(FPV_RD4("%0", "%1", "%2", "%3", "%12", "%13") FPV_RD4("%4", "%5", "%6", "%7", "%14", "%15")
+                         FPV_RD4("%8", "%9", "%10", "%11", "%16", "%17") "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(h4[0]), "=&v"(l4[0]), "=&v"(dh4[0]), "=&v"(dl4[0]), "=&v"(h4[1]), "=&v"(l4[1]), "=&v"(dh4[1]), "=&v"(dl4[1]),
+                           "=&v"(h4[2]), "=&v"(l4[2]), "=&v"(dh4[2]), "=&v"(dl4[2])
+                         : "v"(ra[0]), "v"(pa[0]), "v"(ra[1]), "v"(pa[1]), "v"(ra[2]), "v"(pa[2]), [s1] "n"(S), [s2] "n"(2 * S) : "memory");
+          }
+#undef FPV_RD4
 #pragma unroll
           for (int k = 0; k < NK; k++) {
             const uint32_t px = s0 + ((k0 + k) * 64 + lane) * 4;

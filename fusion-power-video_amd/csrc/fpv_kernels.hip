@@ -1962,7 +1962,7 @@ __global__ __launch_bounds__(192) void k_inverse_trio(
   uint8_t* rbuf = smem + ring_bytes;    // residual bytes of superstep t at rbuf + (t & (2 M - 1)) * S
   uint8_t* lbuf = rbuf + 2 * M * S;     // low / delta-high / delta-low bytes of the q-th superstep of a block at lbuf + (q * 3 + plane) * S
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  uint32_t role = wave;  // 0 chain, 1 and 2 i/o; frames with a chain reassign it below (claim_chain_simd)
+  uint32_t role = wave;  // 0 chain, 1 and 2 i/o; frames with a chain reassign it below (the SIMD claim)
   const uint32_t frame = blockIdx.x, lane = threadIdx.x & 63;
   const size_t fbase = (size_t)frame * g.npix;
   const uint8_t* hp = high + fbase;

@@ -702,16 +702,21 @@ double fpvhip_time_predict_device(fpvhip_ctx* c, const void* d_frames,
 }
 
 int fpvhip_warmup(int device) {
+  const double t0 = now_ms();
   int n = fpvhip_device_count();
   if (n <= 0) return -1;
   if (device < 0 || device >= n) return fail(nullptr, "device %d out of range", device);
+  const double t_count = now_ms();
   HIPOK(nullptr, hipSetDevice(device));
   HIPOK(nullptr, hipFree(nullptr));  // creates the primary context
+  const double t_ctx = now_ms();
   void* p = nullptr;
   HIPOK(nullptr, hipMalloc(&p, 4096));
+  const double t_malloc = now_ms();
   HIPOK(nullptr, fpvhip::launch_copy(p, p, 0, nullptr, 0));  // loads the code object
   HIPOK(nullptr, hipDeviceSynchronize());
   HIPOK(nullptr, hipFree(p));
+  const double t_code = now_ms();
   // streams are slow to create (the first one of a process tens of ms, later ones 3-10 ms):
   // a context's worth of them goes into the pool; so does the first host registration
   {
@@ -719,9 +724,16 @@ int fpvhip_warmup(int device) {
     for (auto& x : st) x = take_stream(device);
     for (auto& x : st) give_stream(device, x);
   }
+  const double t_streams = now_ms();
   fpvhip::prepare_kernels();  // function attributes of the forward / inverse kernels on this device
+  const double t_attr = now_ms();
   PinnedRegion r;
   if (pinned_alloc(&r, 1 << 16) == 0) pinned_free(&r);
+  if (g_timing)
+    fprintf(stderr, "fpv-mi355x: warmup(device %d): device count (runtime init) %.1f ms, primary context %.1f ms, first malloc %.1f ms, "
+                    "code object + first launch %.1f ms, three streams %.1f ms, kernel attributes %.1f ms, first host registration %.1f ms\n",
+            device, t_count - t0, t_ctx - t_count, t_malloc - t_ctx, t_code - t_malloc, t_streams - t_code, t_attr - t_streams,
+            now_ms() - t_attr);
   return 0;
 }
 
@@ -741,6 +753,7 @@ double fpvhip_slot_elapsed_ms(fpvhip_ctx* c, uint32_t slot) {
 
 const char* fpvhip_forward_kernel_names(fpvhip_ctx* c) {
   if (!c || !c->g.fwd_ok) return "";
+  if (c->g.tile8_ok) return "k_tile8,k_frame8,k_redo8";
   return c->g.tile_ok ? "k_tile,k_tile_decide,k_tile_finish" : "k_stream,k_redo_decide,k_redo_stream";
 }
 

@@ -41,7 +41,7 @@ fpvhip_ctx* AcquireEncoderCtx(int device, uint32_t xs, uint32_t ys, int shift,
       }
     }
   }
-  WarmUpWait();
+  WarmUpWait(kWarmForward);
   fpvhip_ctx* c = fpvhip_create(device, xs, ys, shift, big_endian ? 1 : 0, batch, slots);
   if (!c) return nullptr;
   std::lock_guard<std::mutex> l(g_pool_m);
@@ -104,6 +104,19 @@ void ReleaseEncoderCtx(fpvhip_ctx* ctx) {
   for (fpvhip_ctx* c : drop) fpvhip_destroy(c);
 }
 
+void DiscardEncoderCtx(fpvhip_ctx* ctx) {
+  if (!ctx) return;
+  {
+    std::lock_guard<std::mutex> l(g_pool_m);
+    for (size_t i = 0; i < g_pool.size(); i++)
+      if (g_pool[i].ctx == ctx) {
+        g_pool.erase(g_pool.begin() + i);
+        break;
+      }
+  }
+  fpvhip_destroy(ctx);
+}
+
 fpvhip_ctx* AcquireDecoderCtx(int device, uint32_t xs, uint32_t ys) {
   {
     std::lock_guard<std::mutex> l(g_pool_m);
@@ -114,7 +127,7 @@ fpvhip_ctx* AcquireDecoderCtx(int device, uint32_t xs, uint32_t ys) {
       }
     }
   }
-  WarmUpWait();
+  WarmUpWait(kWarmInverse);
   fpvhip_ctx* c = fpvhip_create_decoder(device, xs, ys, 1, 1);
   if (!c) return nullptr;
   std::lock_guard<std::mutex> l(g_pool_m);
@@ -129,7 +142,7 @@ void ReleaseDecoderCtx(fpvhip_ctx* ctx) { ReleaseEncoderCtx(ctx); }
 std::shared_ptr<InverseEngine> InverseEngine::Create(size_t xs, size_t ys, uint32_t batch,
                                                      uint32_t slots, int device) {
   std::shared_ptr<InverseEngine> e(new InverseEngine());
-  WarmUpWait();
+  WarmUpWait(kWarmInverse);
   e->ctx_ = fpvhip_create_decoder(device, (uint32_t)xs, (uint32_t)ys, batch, slots);
   if (!e->ctx_) {
     fprintf(stderr, "fpv-mi355x: cannot create GPU decoder context: %s\n", fpvhip_last_error(nullptr));

@@ -13,10 +13,12 @@
 // and callback ordering (cc:1076-1230).  No CPU fallback exists.
 #include <brotli/decode.h>
 #include <brotli/encode.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -271,60 +273,101 @@ void AppendCore(const uint8_t* high, const uint8_t* low, uint8_t flags, size_t n
 // (benchmark.cc:153-180): runtime and context creation (hundreds of ms once per process), the
 // first launch of each kernel (1-3 ms) and the first large transfer in either direction (~7 ms:
 // the copy engines' queues are created then) would land inside that timer.  A process that
-// merely links the library must not touch a GPU, so nothing happens at load by default:
-//   FPV_WARMUP=lazy  (default)  a helper thread parked at load time runs the warm-up when the
-//                               first Encoder / decoder object is constructed; whoever needs the
-//                               GPU first waits for it (WarmUpWait)
-//   FPV_WARMUP=eager            the warm-up runs when the library is loaded (round 2's
-//                               behaviour: the benchmark-friendly setting)
+// merely links the library must not touch a GPU -- and must not own a thread either (threads do
+// not survive fork()) -- so nothing at all happens at load by default:
+//   FPV_WARMUP=lazy  (default)  the first Encoder / decoder / Frame object starts a helper thread
+//                               per visible device (FPV_DEVICES) that brings the device up --
+//                               runtime, primary context, code object, stream pool, then one
+//                               small frame through the kernels of the direction that object
+//                               needs; whoever needs the GPU first waits for it (WarmUpWait)
+//   FPV_WARMUP=eager            the warm-up (both directions) runs when the library is loaded
+//                               (round 2's behaviour)
 //   FPV_WARMUP=off / FPV_NO_WARMUP=1   none
+// Every device of FPV_DEVICES is warmed, side by side: with eight GPUs seven of them would
+// otherwise pay their first stream / copy-engine / first-launch costs inside the first session
+// (the reference's analogue is the thread spawn in its constructor, cc:1076-1084).
 namespace {
-void WarmUpNow() {
-  if (fpvhip_device_count() <= 0) return;
-  int first = 0;
-  if (const char* e = getenv("FPV_DEVICES")) first = atoi(e);
-  if (fpvhip_warmup(first)) return;
-  // one frame through the ordinary forward and inverse entry points; the common kernel
-  // variants (little-endian input with a low plane) are the ones this frame takes
-  const uint32_t wx = 1024, wy = 1024;
-  if (fpvhip_ctx* c = fpvhip_create(first, wx, wy, 4, 0, 1, 1)) {
-    std::vector<uint16_t> img((size_t)wx * wy, 0x0123);
+double WarmNowMs() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// One small frame through the ordinary entry points of the wanted directions; the common kernel
+// variants (little-endian input with a low plane) are the ones this frame takes.
+void WarmDevice(int dev, int dirs) {
+  const bool timing = getenv("FPV_TIMING") != nullptr;
+  const double t0 = WarmNowMs();
+  if (fpvhip_warmup(dev)) return;
+  const double t1 = WarmNowMs();
+  const uint32_t wx = 512, wy = 256;  // every launch and both transfer directions once; the size does not matter
+  if (fpvhip_ctx* c = (dirs & kWarmForward) ? fpvhip_create(dev, wx, wy, 4, 0, 1, 1) : fpvhip_create_decoder(dev, wx, wy, 1, 1)) {
+    std::vector<uint16_t> img((size_t)wx * wy);
     for (size_t i = 0; i < img.size(); i++) img[i] = (uint16_t)((i * 37) & 0xfff);
     const uint8_t *h, *l, *pv, *fl;
     const uint16_t* px;
-    if (fpvhip_set_delta_raw(c, img.data()) == 0) {
-      memcpy(fpvhip_stage_in(c, 0, 0), img.data(), img.size() * 2);
-      if (fpvhip_predict_submit(c, 0, 1, 1) == 0 && fpvhip_predict_wait(c, 0, &h, &l, &pv, &fl) == 0) {
-        const uint8_t f = fl[0] | 2;  // through the speculative inverse as well
-        if (fpvhip_inverse_submit(c, 0, 1, &f) == 0) fpvhip_inverse_wait(c, 0, &px);
+    uint8_t f = 3;
+    bool ok = true;
+    if (dirs & kWarmForward) {
+      ok = fpvhip_set_delta_raw(c, img.data()) == 0;
+      if (ok) {
+        memcpy(fpvhip_stage_in(c, 0, 0), img.data(), img.size() * 2);
+        ok = fpvhip_predict_submit(c, 0, 1, 1) == 0 && fpvhip_predict_wait(c, 0, &h, &l, &pv, &fl) == 0;
+        if (ok) f = fl[0] | 2;  // through the speculative inverse as well
+      }
+    } else {
+      ok = fpvhip_set_delta_decoded(c, img.data()) == 0;
+      if (ok) {
+        memset(fpvhip_stage_plane(c, 0, 0, 0), 1, img.size());
+        memset(fpvhip_stage_plane(c, 0, 0, 1), 2, img.size());
       }
     }
+    if (ok && (dirs & kWarmInverse) && fpvhip_inverse_submit(c, 0, 1, &f) == 0) fpvhip_inverse_wait(c, 0, &px);
     fpvhip_destroy(c);
   }
+  if (timing)
+    fprintf(stderr, "fpv-mi355x: warm-up of device %d: bring-up %.1f ms, first frame (%s%s) %.1f ms\n", dev, t1 - t0,
+            (dirs & kWarmForward) ? "forward" : "", (dirs & kWarmInverse) ? " inverse" : "", WarmNowMs() - t1);
+}
+
+void WarmUpNow(int dirs) {
+  if (fpvhip_device_count() <= 0) return;
+  const std::vector<int> devs = DeviceList();
+  std::vector<int> uniq;
+  for (int d : devs)
+    if (std::find(uniq.begin(), uniq.end(), d) == uniq.end()) uniq.push_back(d);
+  std::vector<std::thread> th;
+  for (size_t i = 1; i < uniq.size(); i++) th.emplace_back(WarmDevice, uniq[i], dirs);
+  if (!uniq.empty()) WarmDevice(uniq[0], dirs);
+  for (auto& t : th) t.join();
 }
 
 struct WarmUp {
   std::mutex m;
   std::condition_variable cv;
-  int state = 0;  // 0 parked, 1 requested, 2 running, 3 done
+  int state = 0;    // 0 idle, 2 running, 3 done
+  int done_dirs = 0;  // directions warmed so far
   enum Mode { kLazy, kEager, kOff } mode = kLazy;
   WarmUp() {
     const char* e = getenv("FPV_WARMUP");
     if (getenv("FPV_NO_WARMUP") || (e && !strcmp(e, "off"))) mode = kOff;
     else if (e && !strcmp(e, "eager")) mode = kEager;
-    if (mode == kOff) { state = 3; return; }
+    if (mode == kOff) { state = 3; done_dirs = kWarmForward | kWarmInverse; return; }
     if (mode == kEager) {  // at load, before main(): nothing of it lands in anybody's timer
-      WarmUpNow();
+      WarmUpNow(kWarmForward | kWarmInverse);
       state = 3;
-      return;
+      done_dirs = kWarmForward | kWarmInverse;
     }
-    std::thread([this] {  // detached: parked until somebody asks, never joined
-      std::unique_lock<std::mutex> l(m);
-      cv.wait(l, [this] { return state == 1; });
-      state = 2;
-      l.unlock();
-      WarmUpNow();
-      l.lock();
+  }
+  // Starts the helper for the directions not warmed yet (m held).  The helper is created here,
+  // on demand, never at load: a process forked after loading the library has no threads of the
+  // parent, and a parked helper it relied on would never answer.
+  void StartLocked(int dirs) {
+    const int want = dirs & ~done_dirs;
+    if (!want || state == 2) return;  // (a running warm-up of another direction: the next request picks it up)
+    state = 2;
+    std::thread([this, want] {
+      WarmUpNow(want);
+      std::lock_guard<std::mutex> l(m);
+      done_dirs |= want;
       state = 3;
       cv.notify_all();
     }).detach();
@@ -334,28 +377,37 @@ WarmUp& TheWarmUp() {
   static WarmUp* w = new WarmUp();  // leaked on purpose: the helper thread may outlive static destruction
   return *w;
 }
+// A child forked while a warm-up was running inherits "running" without the thread that would
+// finish it: start over (the HIP runtime does not survive fork() either; the child's first
+// object then fails with the runtime's own error instead of hanging here).
+void WarmUpAfterFork() {
+  WarmUp& w = TheWarmUp();
+  new (&w.m) std::mutex();
+  new (&w.cv) std::condition_variable();
+  if (w.state == 2) w.state = w.done_dirs ? 3 : 0;
+}
 struct WarmUpAtLoad {
-  WarmUpAtLoad() { TheWarmUp(); }  // starts the (parked) helper thread; touches no GPU unless FPV_WARMUP=eager
+  WarmUpAtLoad() {
+    TheWarmUp();  // reads FPV_WARMUP; touches no GPU and starts no thread unless FPV_WARMUP=eager
+    pthread_atfork(nullptr, nullptr, WarmUpAfterFork);
+  }
 } g_warm_up_at_load;
 }  // namespace
 
-void WarmUpRequest() {
+void WarmUpRequest(int dirs) {
   WarmUp& w = TheWarmUp();
   std::lock_guard<std::mutex> l(w.m);
-  if (w.state == 0) {
-    w.state = 1;
-    w.cv.notify_all();
-  }
+  w.StartLocked(dirs);
 }
 
-void WarmUpWait() {
+void WarmUpWait(int dirs) {
   WarmUp& w = TheWarmUp();
   std::unique_lock<std::mutex> l(w.m);
-  if (w.state == 0) {
-    w.state = 1;
-    w.cv.notify_all();
+  for (;;) {
+    if ((w.done_dirs & dirs) == dirs) return;
+    w.StartLocked(dirs);
+    w.cv.wait(l, [&w] { return w.state != 2; });
   }
-  w.cv.wait(l, [&w] { return w.state == 3; });
 }
 
 }  // namespace internal
@@ -445,7 +497,9 @@ struct Encoder::Impl {
   const bool print_stats = getenv("FPV_STATS") != nullptr;
   const bool stats = true;  // a handful of clock reads per frame
   std::atomic<uint64_t> st_brotli_ns{0}, st_copy_ns{0}, st_gpu_wait_ns{0}, st_gpu_us{0}, st_batches{0}, st_bytes_up{0}, st_bytes_down{0};
-  double last_stats[10] = {};  // filled by Finish (Encoder::LastStats)
+  static constexpr size_t kMaxStatDevs = 16;
+  std::atomic<uint64_t> st_dev_batches[kMaxStatDevs] = {}, st_dev_wait_ns[kMaxStatDevs] = {};  // per device of the session
+  double last_stats[11 + 2 * kMaxStatDevs] = {};  // filled by Finish (Encoder::LastStats)
   std::chrono::steady_clock::time_point st_t0;
   static uint64_t NowNs() {
     return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(
@@ -620,7 +674,9 @@ struct Encoder::Impl {
       const bool ok = CheckHip(fpvhip_predict_wait(ctxs[b->dev], b->slot, &b->high, &b->low, &b->pv, &b->flags),
                                ctxs[b->dev], "fpvhip_predict_wait");
       if (ok && stats) {
-        st_gpu_wait_ns += NowNs() - tw;
+        const uint64_t waited = NowNs() - tw;
+        st_gpu_wait_ns += waited;
+        if (d < kMaxStatDevs) { st_dev_batches[d]++; st_dev_wait_ns[d] += waited; }
         const double ms = fpvhip_slot_elapsed_ms(ctxs[b->dev], b->slot);
         if (ms > 0) st_gpu_us += (uint64_t)(ms * 1000.0);
         st_batches++;
@@ -756,7 +812,7 @@ struct Encoder::Impl {
 
   void ReleaseContexts() {
     for (size_t i = 0; i < ctxs.size(); i++) {
-      if (failed.load()) fpvhip_destroy(ctxs[i]);  // a context that saw an error is not cached for the next session
+      if (failed.load()) DiscardEncoderCtx(ctxs[i]);  // a context that saw an error is not cached for the next session
       else ReleaseEncoderCtx(ctxs[i]);
     }
     ctxs.clear();
@@ -765,7 +821,7 @@ struct Encoder::Impl {
 
 Encoder::Encoder(size_t num_threads, int shift_to_left_align, bool big_endian)
     : impl_(new Impl(num_threads, shift_to_left_align, big_endian)) {
-  WarmUpRequest();  // FPV_WARMUP=lazy: the device warm-up starts now, on the helper thread
+  WarmUpRequest(kWarmForward);  // FPV_WARMUP=lazy: the device warm-up starts now, on helper threads
 }
 
 const char* Encoder::LastError() const { return impl_->failed.load() ? impl_->error.c_str() : ""; }
@@ -781,7 +837,7 @@ Encoder::~Encoder() {
 size_t Encoder::MaxQueued() const { return impl_->max_queued; }
 
 size_t Encoder::LastStats(double* out, size_t n) const {
-  const size_t k = std::min<size_t>(n, 10);
+  const size_t k = std::min<size_t>(n, sizeof impl_->last_stats / sizeof impl_->last_stats[0]);
   for (size_t i = 0; i < k; i++) out[i] = impl_->last_stats[i];
   return k;
 }
@@ -790,7 +846,7 @@ void Encoder::Init(const uint16_t* delta_frame, size_t xsize, size_t ysize,
                    Callback callback, void* payload) {
   Impl& s = *impl_;
   if (s.initialized) Fatal("Encoder::Init", "called twice");
-  WarmUpWait();
+  WarmUpWait(kWarmForward);
   const bool timing = getenv("FPV_TIMING") != nullptr;
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t_start = now();
@@ -972,6 +1028,12 @@ void Encoder::Finish(Callback callback, void* payload) {
     o[0] = (double)n; o[1] = wall; o[2] = brotli; o[3] = copy; o[4] = gpu / batches; o[5] = batches;
     o[6] = s.st_bytes_up / (wall * 1e6); o[7] = s.st_bytes_down / (wall * 1e6);  // GB/s
     o[8] = host_stage / wall; o[9] = s.st_gpu_wait_ns / 1e6;
+    const size_t nd = std::min(s.devices.size(), Impl::kMaxStatDevs);
+    o[10] = (double)nd;
+    for (size_t d = 0; d < nd; d++) {
+      o[11 + 2 * d] = (double)s.st_dev_batches[d].load();
+      o[12 + 2 * d] = s.st_dev_wait_ns[d].load() / 1e6;
+    }
     if (s.print_stats)
       fprintf(stderr,
               "fpv-mi355x: stats: %zu frames %zux%zu, wall %.1f ms (%.1f fps); Brotli %.1f ms + staging copies %.1f ms over %zu "

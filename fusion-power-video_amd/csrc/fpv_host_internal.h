@@ -37,10 +37,12 @@ bool BrotliInto(const uint8_t* in, size_t size, size_t* pos, uint8_t* dst,
 // Brotli of the planes of a batch, in both directions -- do not pay for thread creation.
 void ParallelFor(size_t n, size_t threads, const std::function<void(size_t)>& fn);
 
-// Device warm-up (fpv_host.cc): Request starts it on the helper thread if it has not run yet
-// (object constructors), Wait also blocks until it is done (whoever is about to create a context).
-void WarmUpRequest();
-void WarmUpWait();
+// Device warm-up (fpv_host.cc): Request starts it on helper threads (one per visible device) for
+// the directions that have not been warmed yet (object constructors), Wait also blocks until they
+// are done (whoever is about to create a context).
+enum { kWarmForward = 1, kWarmInverse = 2 };
+void WarmUpRequest(int dirs);
+void WarmUpWait(int dirs);
 
 std::vector<int> DeviceList();
 size_t EnvSize(const char* name, size_t dflt);
@@ -55,6 +57,9 @@ void AppendCore(const uint8_t* high, const uint8_t* low, uint8_t flags, size_t n
 fpvhip_ctx* AcquireEncoderCtx(int device, uint32_t xs, uint32_t ys, int shift,
                               bool big_endian, uint32_t batch, uint32_t slots);
 void ReleaseEncoderCtx(fpvhip_ctx* ctx);
+// A context that saw a GPU error: taken out of the cache (so that no later session can be handed
+// it, and a new context at the same address cannot be mistaken for it) and destroyed.
+void DiscardEncoderCtx(fpvhip_ctx* ctx);
 // Same cache for small inverse contexts (batch 1, one slot) used by Frame::Uncompress.
 fpvhip_ctx* AcquireDecoderCtx(int device, uint32_t xs, uint32_t ys);
 void ReleaseDecoderCtx(fpvhip_ctx* ctx);

@@ -21,6 +21,7 @@
 #include "fpv_kernels.h"
 
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 #include <mutex>
@@ -1130,6 +1131,7 @@ __device__ __forceinline__ void lds_barrier() {
 }
 
 #include "fpv_tile.inc"
+#include "fpv_tile8.inc"
 
 // ---- exact redo of mis-speculated frames (list driven) ----
 
@@ -2560,6 +2562,35 @@ bool make_geom(uint32_t xs, uint32_t ys, int shift, int big_endian, Geom* g,
       }
     }
   }
+  // Round 4's tile pass (fpv_tile8.inc): a thread per 8-pixel column segment of an R-row group,
+  // a workgroup per R * G rows.  R = 4 (62 VGPRs: eight waves per SIMD) and workgroups of 1024
+  // threads, two per CU (measured at 1280x800, same process: R = 4 / G = 6 0.749 ms, R = 4 / G = 3
+  // 0.782 -- twice the halo rows and records --, R = 8 / G = 3 0.788, R = 8 / G = 6 0.966: one
+  // workgroup per CU; profiles/r04_forward_ab.log).
+  {
+    const uint32_t ncs = xs / 8;
+    uint32_t R = 4;
+    if (const char* e = getenv("FPV_TILE8_ROWS")) R = atoi(e) == 8 ? 8u : 4u;
+    uint32_t G = ncs ? 1024u / ncs : 0;
+    if (const char* e = getenv("FPV_TILE8_GROUPS")) G = std::max(1u, (uint32_t)atoi(e));
+    if (ncs && G * ncs > 1024) G = 1024 / ncs;
+    G = std::min(G, (ys + R - 1) / R);
+    const char* fwd = getenv("FPV_FORWARD");  // "stream" / "tile16": the earlier kernels (A/B runs, tests)
+    g->tile8_ok = 0;
+    if (g->tile_ok && G >= 1 && !(fwd && (fwd[0] == 's' || !strcmp(fwd, "tile16")))) {
+      const uint32_t T = std::max(256u, round_up(G * ncs, 256));
+      const uint32_t tiles = (ys + R * G - 1) / (R * G);
+      const uint32_t lds = tile8_lds_bytes(R, G, ncs, T);
+      if (T <= 1024 && tiles <= 65535 && lds <= 64 * 1024) {
+        g->tile8_ok = 1;
+        g->tile8_rows = R;
+        g->tile8_groups = G;
+        g->tile8_threads = T;
+        g->tile8_tiles = tiles;
+        g->tile8_lds = lds;
+      }
+    }
+  }
   g->nd = (g->npix + 14) / 15;
   g->ncg = g->npix > xs + 1 ? (g->npix - xs - 1 + 30) / 31 : 0;
   uint32_t ring = 1;
@@ -2599,7 +2630,7 @@ size_t fwd_workspace_bytes(const Geom& g, uint32_t max_frames) {
   size_t b = 512 + 2 * (size_t)round_up(max_frames * 4, 256);    // counter blocks, anylow, frame_done
   b += round_up((size_t)max_frames * g.redo_strips * 4, 256);    // boundary words
   if (g.tile_ok) {
-    b += round_up((size_t)max_frames * g.tile_tiles * kTileRecBytes, 256);  // tile records
+    b += round_up((size_t)max_frames * std::max(g.tile_tiles, g.tile8_ok ? g.tile8_tiles : 0u) * kTileRecBytes, 256);  // tile records
     b += round_up((size_t)max_frames * g.npv, 256);              // raw previews
     b += round_up(max_frames * 4, 256);                          // per-position prediction
   }
@@ -2626,7 +2657,7 @@ void carve_fwd_workspace(const Geom& g, uint32_t max_frames, void* base,
   ws->zero_bytes = (size_t)(p - static_cast<uint8_t*>(base));
   if (g.tile_ok) {
     ws->trec = p;
-    p += round_up((size_t)max_frames * g.tile_tiles * kTileRecBytes, 256);
+    p += round_up((size_t)max_frames * std::max(g.tile_tiles, g.tile8_ok ? g.tile8_tiles : 0u) * kTileRecBytes, 256);
     ws->pvraw = p;
     p += round_up((size_t)max_frames * g.npv, 256);
     ws->spec_pos = reinterpret_cast<uint32_t*>(p);
@@ -2742,7 +2773,44 @@ static hipError_t predict_impl(const Geom& g, const uint16_t* d_frames,
                                uint8_t* d_preview, uint8_t* d_flags,
                                hipStream_t s, hipEvent_t* ev) {
   const int with_delta = d_dhigh != nullptr;
-  if (g.tile_ok && ws.trec) {  // dispatch-ordered tiles (fpv_tile.inc)
+  if (g.tile8_ok && ws.trec) {  // dispatch-ordered tiles, 8 pixels per lane (fpv_tile8.inc)
+    if ((uint64_t)nframes * g.tile8_tiles > 0x7fffffffull) return hipErrorInvalidValue;  // one workgroup per tile
+    TileLaunch L;
+    TileArgs& a = L.g;
+    a.xs = g.xs; a.ys = g.ys; a.npix = g.npix; a.pw = g.pw; a.npv = g.npv;
+    a.ncs = g.xs / 8; a.groups = g.tile8_groups; a.tiles = g.tile8_tiles; a.nitems = a.groups * a.ncs;
+    a.shift = (uint32_t)g.shift; a.nframes = nframes; a.with_delta = (uint32_t)with_delta;
+    a.in_pitch = a.out_pitch = g.npix;
+    a.xs15 = g.xs % 15u; a.xs31 = g.xs % 31u; a.c31 = (g.xs + 1u) % 31u; a.ncg = g.ncg;
+    TilePtrs& P = L.P;
+    P.frames = d_frames; P.dhigh = d_dhigh; P.dlow = d_dlow;
+    P.high = d_high; P.low = d_low; P.preview = d_preview; P.flags = d_flags;
+    P.trec = ws.trec; P.pvraw = ws.pvraw;
+    P.ctr = ws.ctr + (ws.seq & 1u) * 64;
+    P.ctr_next = ws.ctr + ((ws.seq + 1) & 1u) * 64;
+    ws.seq++;
+    P.decision = ws.decision; P.list_a = ws.list_a; P.list_b = ws.list_b; P.spec = reinterpret_cast<uint32_t*>(ws.spec); P.spec_pos = ws.spec_pos;
+    const bool lowp = g.shift != 8;
+    const uint32_t T = g.tile8_threads, lds = g.tile8_lds, grid = nframes * g.tile8_tiles;
+    const uint32_t rgrid = std::min<uint32_t>(grid, device_cus() * std::max(1u, 2048u / T));
+    if (ev) hipEventRecord(ev[0], s);
+#define FPV_T8(K, GRID) \
+    do { \
+      if (g.tile8_rows == 8) { if (lowp) K<SWAP, true, 8><<<GRID, T, lds, s>>>(L); else K<SWAP, false, 8><<<GRID, T, lds, s>>>(L); } \
+      else { if (lowp) K<SWAP, true, 4><<<GRID, T, lds, s>>>(L); else K<SWAP, false, 4><<<GRID, T, lds, s>>>(L); } \
+    } while (0)
+    FPV_T8(k_tile8, grid);
+    if (ev) hipEventRecord(ev[1], s);
+    if (g.tile8_tiles > 64) k_frame8<SWAP, true><<<2 * nframes, 1024, 0, s>>>(L);   // many records per frame (large frames)
+    else k_frame8<SWAP, false><<<2 * nframes, 256, 0, s>>>(L);
+    if (ev) hipEventRecord(ev[2], s);
+    FPV_T8(k_redo8, rgrid);
+#undef FPV_T8
+    if (ev) hipEventRecord(ev[3], s);
+    if (ev) hipEventRecord(ev[4], s);
+    return hipGetLastError();
+  }
+  if (g.tile_ok && ws.trec) {  // round 3's tiles, 16 pixels per lane (fpv_tile.inc)
     if ((uint64_t)nframes * g.tile_tiles > 0x7fffffffull) return hipErrorInvalidValue;  // one workgroup per tile
     TileLaunch L;
     TileArgs& a = L.g;

@@ -203,8 +203,9 @@ class Encoder {
   // Finish.  out[0] frames, [1] wall ms since Init, [2] Brotli ms and [3] staging-copy ms
   // summed over the workers, [4] mean GPU batch latency ms (copy in + kernels + copy out),
   // [5] batches, [6] GB/s copied in and [7] out over the wall time, [8] host stage
-  // (Brotli + copies, per thread) / wall, [9] ms the dispatcher waited for the GPU.
-  // Returns the number of values written (at most n).
+  // (Brotli + copies, per thread) / wall, [9] ms the dispatchers waited for the GPU, [10] devices
+  // of the session D, then per device d < D (at most 16): [11 + 2 d] batches it took, [12 + 2 d]
+  // ms its dispatcher waited for it.  Returns the number of values written (at most n).
   size_t LastStats(double* out, size_t n) const;
   // Extension: the session's first GPU failure ("" while there is none).  The upstream API is
   // void everywhere; after a failure the session accepts no more frames (their callbacks never

@@ -76,13 +76,17 @@ while time.time() - t0 < budget:
     os.environ["FPV_INVERSE"] = str(rng.choice(["spec", "trio", "auto", "fast"], p=[0.4, 0.4, 0.1, 0.1]))  # read per launch
     # forward path (read when the context is created): the tile pass with a random tile height where the
     # width allows it (multiples of 64), now and then the streaming kernels instead
-    os.environ.pop("FPV_TILE_GROUPS", None)
-    os.environ.pop("FPV_FORWARD", None)
-    r = int(rng.integers(0, 8))
+    for k in ("FPV_TILE_GROUPS", "FPV_FORWARD", "FPV_TILE8_GROUPS", "FPV_TILE8_ROWS"):
+        os.environ.pop(k, None)
+    r = int(rng.integers(0, 12))
     if r == 0:
         os.environ["FPV_FORWARD"] = "stream"
-    elif r < 4:
+    elif r < 3:     # round 3's tile pass (16 pixels per lane)
+        os.environ["FPV_FORWARD"] = "tile16"
         os.environ["FPV_TILE_GROUPS"] = str(int(rng.integers(1, 24)))
+    elif r < 9:     # round 4's tile pass (8 pixels per lane): 4 or 8 rows per thread, random tile height
+        os.environ["FPV_TILE8_ROWS"] = str(int(rng.choice([4, 8])))
+        os.environ["FPV_TILE8_GROUPS"] = str(int(rng.integers(1, 24)))
     p = pkg.Predictor(xs, ys, shift, be, max_batch=n)
     if delta is not None:
         p.set_delta_raw(delta)

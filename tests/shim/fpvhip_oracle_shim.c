@@ -23,9 +23,18 @@
  *   FPV_SHIM_DELAY=<dev>:<ms> fpvhip_predict_wait on contexts of device <dev> sleeps <ms> first
  *                             (a slow GPU); fpvhip_shim_overlapped_waits() counts the waits of
  *                             OTHER devices that returned while such a sleep was in progress
- *   FPV_SHIM_FAIL_WAIT=<k>    the k-th fpvhip_predict_wait made while the variable is set (1-based) fails */
+ *   FPV_SHIM_FAIL_WAIT=<k>    the k-th fpvhip_predict_wait made while the variable is set (1-based) fails
+ * Bookkeeping the tests read back:
+ *   fpvhip_shim_warmups(dev)      fpvhip_warmup calls seen for the device
+ *   fpvhip_shim_cold_creates()    contexts created on a device that had not been warmed yet */
 static int g_delayed_active, g_overlapped, g_waits;
+static int g_warmups[64], g_cold_creates;
 int fpvhip_shim_overlapped_waits(void) { return __atomic_load_n(&g_overlapped, __ATOMIC_SEQ_CST); }
+int fpvhip_shim_warmups(int device) { return __atomic_load_n(&g_warmups[device & 63], __ATOMIC_SEQ_CST); }
+int fpvhip_shim_cold_creates(void) { return __atomic_load_n(&g_cold_creates, __ATOMIC_SEQ_CST); }
+static void note_create(int device) {
+  if (!__atomic_load_n(&g_warmups[device & 63], __ATOMIC_SEQ_CST)) __atomic_add_fetch(&g_cold_creates, 1, __ATOMIC_SEQ_CST);
+}
 
 typedef struct {
   uint16_t *pix;
@@ -51,7 +60,10 @@ int fpvhip_device_count(void) {
   return e ? atoi(e) : 1;
 }
 const char *fpvhip_last_error(const fpvhip_ctx *c) { return c ? c->err : g_err; }
-int fpvhip_warmup(int device) { (void)device; return 0; }
+int fpvhip_warmup(int device) {
+  __atomic_add_fetch(&g_warmups[device & 63], 1, __ATOMIC_SEQ_CST);
+  return 0;
+}
 int fpvhip_prepare_slot(fpvhip_ctx *c, uint32_t slot) { (void)c; (void)slot; return 0; }
 size_t fpvhip_staging_bytes(const fpvhip_ctx *c) { return c ? (size_t)c->nslots * c->batch * c->npix * 4 : 0; }
 int fpvhip_trim(fpvhip_ctx *c) { (void)c; return 0; }
@@ -92,11 +104,12 @@ fpvhip_ctx *fpvhip_create(int device, uint32_t xs, uint32_t ys, int shift, int b
                           uint32_t batch, uint32_t slots) {
   fpvhip_ctx *c = mk(xs, ys, shift, be, batch, slots, 1);
   if (c) c->device = device;
+  if (!(xs == 512 && ys == 256 && batch == 1)) note_create(device);  /* (the warm-up's own small context does not count) */
   return c;
 }
 fpvhip_ctx *fpvhip_create_decoder(int device, uint32_t xs, uint32_t ys, uint32_t batch,
                                   uint32_t slots) {
-  (void)device;
+  if (!(xs == 512 && ys == 256 && batch == 1)) note_create(device);
   return mk(xs, ys, 0, 0, batch, slots, 0);
 }
 void fpvhip_destroy(fpvhip_ctx *c) {

@@ -33,16 +33,25 @@ def test_bench_line_contract():
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     # achieved = algorithmic bytes per launch / the dominant kernel's measured duration
-    assert rf["kernel"] == "k_tile"                       # 1280x800 takes the tile pass
+    assert rf["kernel"] == "k_tile8"                      # 1280x800 takes round 4's tile pass (8 pixels per lane)
     k_ms = d["kernel_ms"][rf["kernel"]]
     assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (k_ms / 1e3) / 1e9) / rf["achieved"] < 0.01
     assert k_ms <= d["ms_per_step"] * 1.02
     assert 0.3 < rf["frac"] < 1.0
     # traffic is measured in the run itself (rocprofv3 --pmc child processes); the PMC bytes can
-    # only exceed the algorithmic ones, and not by much
-    assert "traffic_error" not in rf, rf.get("traffic_error")
-    assert rf["traffic"] is not None and "THIS run" in rf["traffic_source"]
-    assert 0.98 * rf["algorithmic_bytes_per_launch"] <= rf["traffic"] <= 1.25 * rf["algorithmic_bytes_per_launch"]
+    # only exceed the algorithmic ones, and not by much.  Without the profiler on the box the line
+    # must still come out, with the reason in it.
+    import shutil
+    if shutil.which("rocprofv3") is None:
+        assert rf["traffic"] is None and "traffic_error" in rf
+    else:
+        assert "traffic_error" not in rf, rf.get("traffic_error")
+        assert rf["traffic"] is not None and "THIS run" in rf["traffic_source"]
+        assert 0.98 * rf["algorithmic_bytes_per_launch"] <= rf["traffic"] <= 1.25 * rf["algorithmic_bytes_per_launch"]
+        adv = d["adversarial"]
+        assert "traffic_error" not in adv and 1.0 < adv["traffic_over_algorithmic"] < 1.8, adv
+    mv = d["value_moving_window"]
+    assert mv["frames_redone_per_step"] > 0 and 0.5 * d["value"] < mv["frames_per_s"] <= 1.05 * d["value"], mv
     # `value` comes from the first allocation; the survey is reported, never selected
     pl = d["placement"]
     assert abs(pl["first_ms"] - d["ms_per_step"]) / d["ms_per_step"] < 0.05
@@ -52,6 +61,32 @@ def test_bench_line_contract():
         assert k in cb, k
     assert cb["kind"] in ("reference", "port") and cb["cores"] == 1 and cb["value"] > 0
     assert d["inverse"]["roundtrip_bit_exact"] is True
+
+
+def test_two_rank_line_carries_what_the_north_star_asks_for():
+    """The multi-GPU line next to the reference CPU encoder on the same host (BASELINE north_star):
+    a 2-rank rehearsal on this box's one GPU (gloo control plane, both ranks on GPU 0) must carry
+    cpu_baseline, the in-process multi-device Encoder figure (e2e_multi: ONE Encoder over both
+    contexts, batches on each) and every rank's kernel times."""
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29617", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "10", "--warmup", "2", "--share-gpu", "--dist-backend", "gloo",
+                        "--placement-survey", "0"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("reference", "port") and cb["value"] > 0
+    em = d["e2e_multi"]
+    assert "error" not in em, em
+    assert em["fps"] > 0 and em["devices"] == [0, 0]
+    assert len(em["stage_split"]["per_device_batches"]) == 2 and min(em["stage_split"]["per_device_batches"]) > 0
+    pr = d["per_rank"]
+    assert len(pr["ms_per_step"]) == 2 and len(pr["kernel_ms"]) == 2 and pr["process_group"]["world_size"] == 2
+    assert all(k["k_tile8"] > 0 for k in pr["kernel_ms"])
+    assert abs(d["value"] - 2 * d["config"]["frames_per_step_per_gpu"] / (d["ms_per_step"] / 1e3)) / d["value"] < 0.01
 
 
 def test_forward_rate_does_not_depend_on_where_the_buffers_lie(fpv, synth):

@@ -279,6 +279,98 @@ def test_gpu_failure_is_latched_not_fatal(tmp_path):
     assert out.returncode != 0 and "fatal" in out.stderr
 
 
+_WARM_SCRIPT = r'''
+import sys, os, importlib, hashlib, ctypes
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+from conftest import load_package
+load_package()
+synth = importlib.import_module("fpv_amd.synth"); codec = importlib.import_module("fpv_amd.codec").Codec(sys.argv[2])
+lib = ctypes.CDLL(sys.argv[2])
+ndev = int(os.environ["FPV_SHIM_DEVICES"])
+print("LOADED", " ".join(str(lib.fpvhip_shim_warmups(d)) for d in range(ndev)))   # nothing at load
+fr = synth.noise_frames(64, 64, 48, seed=9)
+fpv = codec.encode_stream(fr, fr[0], 64, 48, threads=4)
+print("SHA", hashlib.sha256(fpv.tobytes()).hexdigest())
+print("AFTER_ENCODE", " ".join(str(lib.fpvhip_shim_warmups(d)) for d in range(ndev)))
+print("COLD", lib.fpvhip_shim_cold_creates())
+import numpy as np
+dec = codec.decode_stream(fpv, batched=True, threads=4)
+assert np.array_equal(dec, fr)
+fpv2 = codec.encode_stream(fr, fr[0], 64, 48, threads=2)                            # a second session: nothing is warmed twice
+assert np.array_equal(fpv2, fpv)
+print("AFTER_ALL", " ".join(str(lib.fpvhip_shim_warmups(d)) for d in range(ndev)))
+print("COLD_END", lib.fpvhip_shim_cold_creates())
+'''
+
+
+def test_every_device_is_warmed_once_before_its_first_context(tmp_path):
+    """Eight devices (FPV_DEVICES unset = all): loading the library warms nothing; the first
+    Encoder warms EVERY device for the forward direction (one fpvhip_warmup each) before any
+    context is created on it; the first decoder adds one more bring-up per device for the inverse
+    direction, and later sessions warm nothing again.  Reference analogue: the thread spawn in the
+    Encoder constructor, cc:1076-1084."""
+    import subprocess
+    import sys
+    if not os.path.exists(SHIM):
+        pytest.skip("tests/shim not built")
+    script = tmp_path / "warm.py"
+    script.write_text(_WARM_SCRIPT)
+    for devs, expect in ((None, range(8)), ("5,2,5", (2, 5))):
+        env = dict(os.environ, FPV_SHIM_DEVICES="8", FPV_BATCH="4", FPV_DECODE_BATCH="16")
+        env.pop("FPV_WARMUP", None)
+        if devs:
+            env["FPV_DEVICES"] = devs
+        out = subprocess.run([sys.executable, str(script), os.path.dirname(HERE), SHIM], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout + out.stderr
+        res = {l.split(" ", 1)[0]: l.split(" ", 1)[1] for l in out.stdout.splitlines() if l[:1].isupper() and " " in l}
+        assert res["LOADED"].split() == ["0"] * 8
+        want = ["1" if d in expect else "0" for d in range(8)]
+        assert res["AFTER_ENCODE"].split() == want, res
+        assert res["COLD"] == "0" and res["COLD_END"] == "0", res
+        assert res["AFTER_ALL"].split() == ["2" if d in expect else "0" for d in range(8)], res
+
+
+_FAIL_THEN_OK_SCRIPT = r'''
+import sys, os, importlib, hashlib
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+from conftest import load_package
+load_package()
+synth = importlib.import_module("fpv_amd.synth"); codec = importlib.import_module("fpv_amd.codec").Codec(sys.argv[2])
+fr = synth.noise_frames(96, 64, 48, seed=9)
+good = codec.encode_stream(fr, fr[0], 64, 48, threads=4)          # fills the context cache
+os.environ["FPV_SHIM_FAIL_WAIT"] = "4"
+mq, got = codec.encode_with_callbacks(fr, fr[0], 64, 48, threads=4)
+print("ERR1", codec.last_error)
+os.environ.pop("FPV_SHIM_FAIL_WAIT")
+for k in range(3):                                                 # the failed session's contexts are gone, not cached
+    again = codec.encode_stream(fr, fr[0], 64, 48, threads=4)
+    assert hashlib.sha256(again.tobytes()).digest() == hashlib.sha256(good.tobytes()).digest(), k
+other = codec.encode_stream(fr[:, :32, :], fr[0, :32, :].copy(), 64, 32, threads=4)   # another geometry in between
+again = codec.encode_stream(fr, fr[0], 64, 48, threads=4)
+assert hashlib.sha256(again.tobytes()).digest() == hashlib.sha256(good.tobytes()).digest()
+print("ERR2", codec.last_error)
+print("OK")
+'''
+
+
+def test_failed_session_then_more_sessions_in_one_process(tmp_path):
+    """A session that latched a GPU failure destroys its contexts; they must also leave the
+    process-wide cache (a dangling entry marked busy would otherwise stay there, and a new context
+    at the same address would flip it to idle: two sessions on one context).  Sessions that
+    follow in the same process, same and other geometry, two devices, produce the reference
+    bytes."""
+    import subprocess
+    import sys
+    if not os.path.exists(SHIM):
+        pytest.skip("tests/shim not built")
+    script = tmp_path / "fail_then_ok.py"
+    script.write_text(_FAIL_THEN_OK_SCRIPT)
+    out = subprocess.run([sys.executable, str(script), os.path.dirname(HERE), SHIM],
+                         env=dict(os.environ, FPV_SHIM_DEVICES="2", FPV_BATCH="4"), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+    assert "injected failure" in out.stdout.split("ERR1", 1)[1].splitlines()[0]
+
+
 def test_fuzzed_streams_never_crash(codec):
     """Random byte flips, truncations and splices: every decoder entry either
     succeeds or reports failure; none may crash or read out of bounds."""

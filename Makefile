@@ -98,7 +98,11 @@ endif
 # the CPU test shim, and (where the upstream tree is present) the upstream columnar
 # tests compiled UNCHANGED against OUR columnar headers (symlinked so that their quoted
 # includes resolve to include/columnar_batch/).
-columnar: $(BINDIR)/columnar_driver tests/shim/columnar_driver_cpushim $(BINDIR)/columnar_dump tests/shim/columnar_dump_cpushim
+columnar: $(BINDIR)/columnar_driver tests/shim/columnar_driver_cpushim $(BINDIR)/columnar_dump tests/shim/columnar_dump_cpushim tests/shim/adapter_fail_cpushim
+# GPU failures inside the adapters are latched, never fatal (tests/adapter_fail_driver.cc; CPU shim only: it injects them)
+tests/shim/adapter_fail_cpushim: tests/adapter_fail_driver.cc tests/shim/libfpv_amd_cpushim.so $(wildcard include/columnar_batch/*.h)
+	$(CXX) -std=c++14 -O2 -Wall -Iinclude/columnar_batch $< tests/shim/libfpv_amd_cpushim.so -lpthread \
+	    -Wl,-rpath,'$$ORIGIN' -o $@
 # format-parity dump of the native Batch (tests/columnar_dump.cc; the reference build of the same
 # source lives in oracle/_ref)
 $(BINDIR)/columnar_dump: tests/columnar_dump.cc $(LIBDIR)/libfpv_amd.so $(wildcard include/columnar_batch/*.h)
@@ -208,9 +212,12 @@ build/asan/libfpv_amd_cpushim.so: tests/shim/fpvhip_oracle_shim.c oracle/fpv_ora
 	$(CXX) $(CXXFLAGS) -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -shared -Wl,-Bsymbolic $(HOST_SRC) build/asan/shim.o build/asan/oracle.o $(BROTLI) -o $@
 
 # ThreadSanitizer run of the threaded host paths (native driver; CPU only).
-tsan: build/tsan/driver build/tsan/columnar
+tsan: build/tsan/driver build/tsan/columnar build/tsan/adapter_fail
 	TSAN_OPTIONS=halt_on_error=1 build/tsan/driver
 	TSAN_OPTIONS=halt_on_error=1 build/tsan/columnar
+	TSAN_OPTIONS=halt_on_error=1 build/tsan/adapter_fail
+build/tsan/adapter_fail: tests/adapter_fail_driver.cc build/tsan/driver
+	$(CXX) $(CXXFLAGS) -O1 -g -fsanitize=thread -Iinclude/columnar_batch tests/adapter_fail_driver.cc $(HOST_SRC) build/tsan/shim.o build/tsan/oracle.o $(BROTLI) -o $@
 build/tsan/columnar: tests/columnar_driver.cc build/tsan/driver
 	$(CXX) $(CXXFLAGS) -O1 -g -fsanitize=thread -Iinclude/columnar_batch tests/columnar_driver.cc $(HOST_SRC) build/tsan/shim.o build/tsan/oracle.o $(BROTLI) -o $@
 build/tsan/driver: tests/shim/tsan_driver.cc tests/shim/fpvhip_oracle_shim.c oracle/fpv_oracle.c $(HOST_SRC) $(HOST_HDR)

@@ -28,6 +28,20 @@ struct ArrowEncoder::Impl {
   std::mutex m;
   std::shared_ptr<arrow::Schema> schema;  // made from the first frame
   std::unique_ptr<ColumnarBatchEncoder> columns;
+  // A record batch that could not be built (the GPU side latches in `columns`): kept, printed once.
+  struct Latch {
+    std::mutex m;
+    std::string text_;
+    bool failed() { std::lock_guard<std::mutex> l(m); return !text_.empty(); }
+    std::string text() { std::lock_guard<std::mutex> l(m); return text_; }
+    void Fail(const char* what, const char* detail) {
+      if (getenv("FPV_ABORT_ON_ERROR")) { fprintf(stderr, "fpv-mi355x: fatal: ArrowEncoder: %s: %s\n", what, detail); abort(); }
+      std::lock_guard<std::mutex> l(m);
+      if (!text_.empty()) return;
+      text_ = std::string(what) + ": " + detail;
+      fprintf(stderr, "fpv-mi355x: ArrowEncoder failed: %s (the batch is dropped, later PushFrame calls are refused)\n", text_.c_str());
+    }
+  } latch;
 
   Impl(size_t x, size_t y, int s, bool be, RecordBatchConsumer c, int per_batch)
       : xs(x), ys(y), shift(s), big_endian(be), consumer(std::move(c)) {
@@ -88,9 +102,9 @@ struct ArrowEncoder::Impl {
       s = schema;
     }
     columns->ReturnProcessedBatch(b);  // the columns have been copied into Arrow buffers
-    if (!ok || !s) {
-      fprintf(stderr, "fpv-mi355x: ArrowEncoder: building a record batch failed\n");
-      abort();  // like the other encoders: no error channel, never drop data silently
+    if (!ok || !s) {  // latched (ArrowEncoder::LastError), the batch is dropped, later PushFrame calls are refused
+      latch.Fail("building a record batch failed", !s ? "no schema" : "Arrow builder out of memory");
+      return;
     }
     consumer(arrow::RecordBatch::Make(s, n, {a[0], a[1], a[2], a[3], a[4], a[5]}));
   }
@@ -106,7 +120,13 @@ ArrowEncoder::~ArrowEncoder() {
   impl_.reset();
 }
 
+std::string ArrowEncoder::LastError() const {
+  const std::string own = impl_->latch.text();
+  return own.empty() ? impl_->columns->LastError() : own;
+}
+
 std::future<void*> ArrowEncoder::PushFrame(uint64_t timestamp, uint16_t* frame, void* info) {
+  if (impl_->latch.failed()) return std::future<void*>();
   bool first;
   {
     std::lock_guard<std::mutex> l(impl_->m);
@@ -191,8 +211,12 @@ bool ArrowDecoder::PushRecordBatch(const std::shared_ptr<arrow::RecordBatch>& rb
       return Impl::Fail("a row does not fit the geometry of the schema");
   }
   std::future<columnarbatch::BatchPtr> done = impl_->columns.PushBatch(b);
-  if (!done.valid()) return Impl::Fail("decoder already closed");
-  done.get();
+  if (!done.valid()) return Impl::Fail("decoder already closed or failed (ColumnarBatchDecoder::LastError)");
+  try {
+    done.get();
+  } catch (const std::exception& e) {  // the columnar decoder delivers its failure through the future
+    return Impl::Fail(e.what());
+  }
   return true;
 }
 

@@ -30,6 +30,8 @@
 #include "../../include/columnar_batch/columnar_batch_decoder.h"
 #include "../../include/columnar_batch/columnar_batch_encoder.h"
 #include "fpv_hip.h"
+#include <stdexcept>
+
 #include "fpv_host_internal.h"
 
 namespace fpvc {
@@ -187,6 +189,12 @@ struct ColumnarBatchEncoder::Impl {
 
   fpvhip_ctx* ctx = nullptr;
   SchemaPtr schema;
+  // First GPU (or Brotli) failure of this encoder: latched.  The failing PushFrame's future
+  // carries it as an exception, later PushFrame calls return an invalid future (as after
+  // Close), batches in flight are dropped, Close still answers with the last timestamp that was
+  // stored before the failure.  The reference's convention (cb/columnar_batch_encoder.cc, cc:160-181)
+  // is to report, never to abort.
+  ErrorLatch latch;
 
   std::mutex m;
   std::condition_variable cv;
@@ -207,25 +215,43 @@ struct ColumnarBatchEncoder::Impl {
   Impl(size_t x, size_t y, int s, bool be, BatchProcessor p, int n)
       : xs(x), ys(y), npix(x * y), npv((x / 4) * (y / 4)), shift(s), big_endian(be),
         per_batch((size_t)std::max(1, n)), processor(std::move(p)), closing_future(closing_promise.get_future()) {
-    const int device = DeviceList()[0];
-    ctx = AcquireEncoderCtx(device, (uint32_t)xs, (uint32_t)ys, shift, big_endian, (uint32_t)per_batch, kSlots);
-    if (!ctx) Fatal("ColumnarBatchEncoder", fpvhip_last_error(nullptr));
+    const std::vector<int> devs = DeviceList();
+    if (devs.empty()) {
+      latch.Fail("ColumnarBatchEncoder", "no usable GPU", fpvhip_last_error(nullptr));
+    } else {
+      ctx = AcquireEncoderCtx(devs[0], (uint32_t)xs, (uint32_t)ys, shift, big_endian, (uint32_t)per_batch, kSlots);
+      if (!ctx) latch.Fail("ColumnarBatchEncoder", "fpvhip_create", fpvhip_last_error(nullptr));
+    }
     for (auto& w : workers) w = std::thread(&Impl::Work, this);  // last: everything they touch exists
   }
 
   ~Impl() {
     for (auto& w : workers)
       if (w.joinable()) w.join();
-    if (ctx) ReleaseEncoderCtx(ctx);
+    if (ctx && latch.failed()) DiscardEncoderCtx(ctx);  // a context that saw a failure is not cached
+    else if (ctx) ReleaseEncoderCtx(ctx);
   }
 
-  void SubmitOpenLocked() {  // m held, open_slot has frames
-    if (fpvhip_predict_submit(ctx, (uint32_t)open_slot, (uint32_t)open_ts.size(), 1))
-      Fatal("fpvhip_predict_submit", fpvhip_last_error(ctx));
+  bool Fail(const char* what, const char* detail) {  // m NOT held
+    latch.Fail("ColumnarBatchEncoder", what, detail);
+    cv.notify_all();
+    return false;
+  }
+
+  bool SubmitOpenLocked() {  // m held, open_slot has frames
+    if (latch.failed() || fpvhip_predict_submit(ctx, (uint32_t)open_slot, (uint32_t)open_ts.size(), 1)) {
+      if (!latch.failed()) latch.Fail("ColumnarBatchEncoder", "fpvhip_predict_submit", fpvhip_last_error(ctx));
+      slot_busy[open_slot] = 0;  // the frames of this batch are dropped
+      open_ts.clear();
+      open_slot = -1;
+      cv.notify_all();
+      return false;
+    }
     submitted.push_back(Pending{(uint32_t)open_slot, std::move(open_ts), next_seq++});
     open_ts.clear();
     open_slot = -1;
     cv.notify_all();
+    return true;
   }
 
   BatchPtr TakeBatch() {
@@ -250,7 +276,17 @@ struct ColumnarBatchEncoder::Impl {
         submitted.pop_front();
       }
       const uint8_t *high, *low, *pv, *flags;
-      if (fpvhip_predict_wait(ctx, p.slot, &high, &low, &pv, &flags)) Fatal("fpvhip_predict_wait", fpvhip_last_error(ctx));
+      bool ok = !latch.failed();
+      if (ok && fpvhip_predict_wait(ctx, p.slot, &high, &low, &pv, &flags)) ok = Fail("fpvhip_predict_wait", fpvhip_last_error(ctx));
+      if (!ok) {  // dropped: free the slot, keep the emission order moving
+        std::unique_lock<std::mutex> l(m);
+        slot_busy[p.slot] = 0;
+        cv.notify_all();
+        cv.wait(l, [&] { return next_emit == p.seq; });
+        next_emit++;
+        cv.notify_all();
+        continue;
+      }
       const size_t n = p.ts.size();
       // Brotli of the 3 planes of every frame, frames in parallel (cc:643-688 per plane)
       std::vector<std::vector<uint8_t>> sh(n), sl(n), sp(n);
@@ -258,21 +294,23 @@ struct ColumnarBatchEncoder::Impl {
       // frame-major order, so that low, high and preview planes are in progress at the
       // same time (sixteen threads all on low planes -- the incompressible, memory-heavy
       // ones -- measured ~20 % slower in the Encoder).
+      std::atomic<bool> brotli_ok{true};
       ParallelFor(3 * n, threads, [&](size_t t) {
         const size_t k = t / 3, which = t % 3;
         if (which == 0) {
-          if (!(flags[k] & NO_LOW_BYTES) && !BrotliAppend(low + k * npix, npix, &sl[k])) Fatal("Brotli", "low plane");
+          if (!(flags[k] & NO_LOW_BYTES) && !BrotliAppend(low + k * npix, npix, &sl[k])) brotli_ok = false;
         } else if (which == 1) {
-          if (!BrotliAppend(high + k * npix, npix, &sh[k])) Fatal("Brotli", "high plane");
+          if (!BrotliAppend(high + k * npix, npix, &sh[k])) brotli_ok = false;
         } else if (!BrotliAppend(pv + k * npv, npv, &sp[k])) {
-          Fatal("Brotli", "preview plane");
+          brotli_ok = false;
         }
       });
-      BatchPtr batch = TakeBatch();
-      for (size_t k = 0; k < n; k++)
+      if (!brotli_ok) ok = Fail("Brotli", "compressing a plane failed");
+      BatchPtr batch = ok ? TakeBatch() : nullptr;
+      for (size_t k = 0; ok && k < n; k++)
         if (!batch->AppendCompressed(p.ts[k], flags[k], sh[k].data(), sh[k].size(), sl[k].data(), sl[k].size(),
                                      sp[k].data(), sp[k].size()))
-          Fatal("ColumnarBatchEncoder", "batch column overflow");
+          ok = Fail("ColumnarBatchEncoder", "batch column overflow");
       {
         std::unique_lock<std::mutex> l(m);
         slot_busy[p.slot] = 0;  // the pinned planes have been consumed
@@ -280,9 +318,9 @@ struct ColumnarBatchEncoder::Impl {
         // two workers overlap the Brotli of one batch with the column copies and the
         // processor call of the one before; batches still leave in submission order
         cv.wait(l, [&] { return next_emit == p.seq; });
-        latest_stored = batch->LatestTimestamp();
+        if (ok) latest_stored = batch->LatestTimestamp();
       }
-      processor(batch);  // one batch at a time, in order
+      if (ok) processor(batch);  // one batch at a time, in order
       {
         std::lock_guard<std::mutex> l(m);
         next_emit++;
@@ -315,20 +353,34 @@ ColumnarBatchEncoder::~ColumnarBatchEncoder() {
   impl_.reset();
 }
 
+std::string ColumnarBatchEncoder::LastError() const { return impl_->latch.text(); }
+
+namespace {
+std::future<void*> FailedFuture(const std::string& why) {  // the failure, delivered through the future
+  std::promise<void*> p;
+  p.set_exception(std::make_exception_ptr(std::runtime_error(why)));
+  return p.get_future();
+}
+}  // namespace
+
 std::future<void*> ColumnarBatchEncoder::PushFrame(uint64_t timestamp, uint16_t* frame, void* info) {
   Impl& s = *impl_;
   std::unique_lock<std::mutex> l(s.m);
-  if (s.closing) return std::future<void*>();
+  if (s.closing || s.latch.failed()) return std::future<void*>();
   if (!s.schema) {  // the first frame is the delta frame of the stream (and an ordinary frame too)
     l.unlock();
     Frame delta(s.xs, s.ys, frame, s.shift, s.big_endian, (int64_t)timestamp);
     SchemaPtr schema = std::make_shared<BatchSchema>(s.xs, s.ys, (size_t)s.shift, delta);
-    if (fpvhip_set_delta_raw(s.ctx, frame)) Fatal("fpvhip_set_delta_raw", fpvhip_last_error(s.ctx));
+    if (fpvhip_set_delta_raw(s.ctx, frame)) {
+      s.Fail("fpvhip_set_delta_raw", fpvhip_last_error(s.ctx));
+      return FailedFuture(s.latch.text());
+    }
     l.lock();
     s.schema = schema;
   }
   if (s.open_slot < 0) {
-    s.cv.wait(l, [&] { return !s.slot_busy[0] || !s.slot_busy[1] || !s.slot_busy[2]; });
+    s.cv.wait(l, [&] { return !s.slot_busy[0] || !s.slot_busy[1] || !s.slot_busy[2] || s.latch.failed(); });
+    if (s.latch.failed()) return FailedFuture(s.latch.text());  // a batch in flight failed while this call waited for a slot
     s.open_slot = !s.slot_busy[0] ? 0 : !s.slot_busy[1] ? 1 : 2;
     s.slot_busy[s.open_slot] = 1;
   }
@@ -336,11 +388,17 @@ std::future<void*> ColumnarBatchEncoder::PushFrame(uint64_t timestamp, uint16_t*
   const size_t k = s.open_ts.size();
   l.unlock();
   uint16_t* dst = fpvhip_stage_in(s.ctx, (uint32_t)slot, (uint32_t)k);
-  if (!dst) Fatal("fpvhip_stage_in", fpvhip_last_error(s.ctx));
+  if (!dst) {
+    s.Fail("fpvhip_stage_in", fpvhip_last_error(s.ctx));
+    return FailedFuture(s.latch.text());
+  }
   memcpy(dst, frame, s.npix * 2);  // the caller's buffer is free from here on
   l.lock();
   s.open_ts.push_back((int64_t)timestamp);
-  if (s.open_ts.size() == s.per_batch) s.SubmitOpenLocked();
+  if (s.open_ts.size() == s.per_batch && !s.SubmitOpenLocked()) {
+    l.unlock();
+    return FailedFuture(s.latch.text());
+  }
   l.unlock();
   std::promise<void*> done;
   done.set_value(info);
@@ -360,10 +418,7 @@ std::shared_future<int64_t> ColumnarBatchEncoder::Close() {
     std::lock_guard<std::mutex> l(s.m);
     if (!s.closed) {
       s.closed = true;
-      if (s.open_slot >= 0 && !s.open_ts.empty()) {
-        s.flushed_partial = true;
-        s.SubmitOpenLocked();
-      }
+      if (s.open_slot >= 0 && !s.open_ts.empty()) s.flushed_partial = s.SubmitOpenLocked();
       s.closing = true;
     }
   }
@@ -388,6 +443,7 @@ struct ColumnarBatchDecoder::Impl {
   std::deque<Job> queue;
   SchemaPtr schema;
   std::shared_ptr<InverseEngine> engine;  // full-size or preview geometry, created with the first batch
+  ErrorLatch latch;  // first failure: that batch's future carries it, later PushBatch calls return an invalid future
   int64_t latest = -1;
   std::promise<int64_t> closing_promise;
   std::shared_future<int64_t> closing_future;
@@ -407,7 +463,9 @@ struct ColumnarBatchDecoder::Impl {
     const bool pv = type == Image::PREVIEW;
     const size_t xs = pv ? sc.xsize() / 4 : sc.xsize(), ys = pv ? sc.ysize() / 4 : sc.ysize();
     const uint32_t per = (uint32_t)std::max<size_t>(1, batch.length());
-    engine = InverseEngine::Create(xs, ys, std::max(per, 1u), 2, DeviceList()[0]);
+    const std::vector<int> devs = DeviceList();
+    if (devs.empty()) return false;
+    engine = InverseEngine::Create(xs, ys, std::max(per, 1u), 2, devs[0]);
     if (!engine) return false;
     capacity = per;
     if (!pv) {  // decoded delta frame = the schema's raw planes (cb/columnar_batch.cc:111)
@@ -422,10 +480,11 @@ struct ColumnarBatchDecoder::Impl {
   }
   uint32_t capacity = 0;
 
-  void DecodeBatch(Batch& batch) {
+  bool DecodeBatch(Batch& batch) {
     const size_t n = batch.length();
-    if (n == 0) return;
-    if (!Prepare(batch)) Fatal("ColumnarBatchDecoder", "no GPU decoder");
+    if (n == 0) return true;
+    if (latch.failed()) return false;
+    if (!Prepare(batch)) return latch.Fail("ColumnarBatchDecoder", "no GPU decoder", fpvhip_last_error(nullptr));
     BatchSchema& sc = *batch.schema();
     const bool pv = type == Image::PREVIEW;
     const size_t xs = pv ? sc.xsize() / 4 : sc.xsize(), ys = pv ? sc.ysize() / 4 : sc.ysize(), npix = xs * ys;
@@ -460,7 +519,8 @@ struct ColumnarBatchDecoder::Impl {
       }
       processor(Image(batch.timestamp(i), xs, ys, bpp, type, std::move(data)));
     }, threads);
-    if (!ok) Fatal("ColumnarBatchDecoder", "decoding a batch failed");
+    if (!ok) return latch.Fail("ColumnarBatchDecoder", "decoding a batch failed", "corrupt streams or a GPU failure");
+    return true;
   }
 
   void Work() {
@@ -473,7 +533,10 @@ struct ColumnarBatchDecoder::Impl {
         job = std::move(queue.front());
         queue.pop_front();
       }
-      DecodeBatch(*job.batch);
+      if (!DecodeBatch(*job.batch)) {  // through the channel the signature has: the future
+        job.done.set_exception(std::make_exception_ptr(std::runtime_error(latch.text())));
+        continue;
+      }
       {
         std::lock_guard<std::mutex> l(m);
         if (!job.batch->Empty()) latest = job.batch->LatestTimestamp();
@@ -497,7 +560,7 @@ std::future<BatchPtr> ColumnarBatchDecoder::PushBatch(BatchPtr batch) {
   std::future<BatchPtr> fut;
   {
     std::lock_guard<std::mutex> l(s.m);
-    if (!batch || s.closing) return std::future<BatchPtr>();
+    if (!batch || s.closing || s.latch.failed()) return std::future<BatchPtr>();
     if (!s.schema) s.schema = batch->schema();
     if (s.schema.get() != batch->schema().get()) return std::future<BatchPtr>();
     Impl::Job job;
@@ -508,6 +571,8 @@ std::future<BatchPtr> ColumnarBatchDecoder::PushBatch(BatchPtr batch) {
   s.cv.notify_all();
   return fut;
 }
+
+std::string ColumnarBatchDecoder::LastError() const { return impl_->latch.text(); }
 
 std::shared_future<int64_t> ColumnarBatchDecoder::Close() {
   Impl& s = *impl_;

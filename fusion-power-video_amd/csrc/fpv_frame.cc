@@ -23,30 +23,60 @@ using namespace internal;
 Frame Frame::EMPTY(0, 0);
 
 namespace {
-int FrameDevice() {
+// GPU failures of the Frame API are latched process-wide (Frame::LastError): the method that hit
+// one leaves the frame as it found it, later GPU-touching methods are no-ops until
+// Frame::ClearError().  Every signature here is void (h:75-139); the reference never aborts.
+bool FrameFail(const char* what, const char* detail) { return FrameErrorLatch().Fail("Frame API", what, detail); }
+bool FrameFailed() { return FrameErrorLatch().failed(); }
+
+int FrameDevice() {  // -1 (latched) when no GPU is usable
   const std::vector<int> d = DeviceList();
-  if (d.empty()) Fatal("Frame: no usable GPU", fpvhip_last_error(nullptr));
+  if (d.empty()) {
+    FrameFail("Frame: no usable GPU", fpvhip_last_error(nullptr));
+    return -1;
+  }
   return d[0];
 }
 
-struct Fwd {  // leased forward context (batch 1, one slot)
-  fpvhip_ctx* ctx;
-  Fwd(size_t xs, size_t ys, int shift, bool be)
-      : ctx(AcquireEncoderCtx(FrameDevice(), (uint32_t)xs, (uint32_t)ys, shift, be, 1, 1)) {
-    if (!ctx) Fatal("Frame: fpvhip_create", fpvhip_last_error(nullptr));
+// Leased contexts.  A context that saw a failure is not handed back to the cache.
+struct Fwd {  // forward context (batch 1, one slot)
+  fpvhip_ctx* ctx = nullptr;
+  bool bad = false;
+  Fwd(size_t xs, size_t ys, int shift, bool be) {
+    const int dev = FrameDevice();
+    if (dev < 0) return;
+    ctx = AcquireEncoderCtx(dev, (uint32_t)xs, (uint32_t)ys, shift, be, 1, 1);
+    if (!ctx) FrameFail("Frame: fpvhip_create", fpvhip_last_error(nullptr));
   }
-  ~Fwd() { ReleaseEncoderCtx(ctx); }
-};
-struct Inv {  // leased inverse context
-  fpvhip_ctx* ctx;
-  Inv(size_t xs, size_t ys) : ctx(AcquireDecoderCtx(FrameDevice(), (uint32_t)xs, (uint32_t)ys)) {
-    if (!ctx) Fatal("Frame: fpvhip_create_decoder", fpvhip_last_error(nullptr));
+  ~Fwd() {
+    if (ctx && bad) DiscardEncoderCtx(ctx);
+    else if (ctx) ReleaseEncoderCtx(ctx);
   }
-  ~Inv() { ReleaseDecoderCtx(ctx); }
+  bool Check(int rc, const char* what) {
+    if (rc == 0) return true;
+    bad = true;
+    return FrameFail(what, fpvhip_last_error(ctx));
+  }
 };
-void Check(int rc, fpvhip_ctx* c, const char* what) {
-  if (rc) Fatal(what, fpvhip_last_error(c));
-}
+struct Inv {  // inverse context
+  fpvhip_ctx* ctx = nullptr;
+  bool bad = false;
+  Inv(size_t xs, size_t ys) {
+    const int dev = FrameDevice();
+    if (dev < 0) return;
+    ctx = AcquireDecoderCtx(dev, (uint32_t)xs, (uint32_t)ys);
+    if (!ctx) FrameFail("Frame: fpvhip_create_decoder", fpvhip_last_error(nullptr));
+  }
+  ~Inv() {
+    if (ctx && bad) DiscardEncoderCtx(ctx);
+    else if (ctx) ReleaseDecoderCtx(ctx);
+  }
+  bool Check(int rc, const char* what) {
+    if (rc == 0) return true;
+    bad = true;
+    return FrameFail(what, fpvhip_last_error(ctx));
+  }
+};
 // cc:186-214 into a vector (Frame::Uncompress does not check sizes)
 void BrotliToVector(std::vector<uint8_t>* v) {
   std::vector<uint8_t> out;
@@ -108,6 +138,10 @@ class PredictCombiner {
       else ++d;
     }
     auto it = all->find(key);
+    if (it != all->end() && (it->second->bad_ || !it->second->ctx_)) {  // its context saw a failure: start afresh
+      all->erase(it);
+      it = all->end();
+    }
     if (it != all->end()) {
       it->second->last_used_ms_.store(now);
       return it->second;
@@ -124,14 +158,20 @@ class PredictCombiner {
     return std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
   }
 
-  ~PredictCombiner() { ReleaseEncoderCtx(ctx_); }
+  ~PredictCombiner() {
+    if (ctx_ && bad_) DiscardEncoderCtx(ctx_);
+    else if (ctx_) ReleaseEncoderCtx(ctx_);
+  }
 
   struct Result { const uint8_t *high, *low, *preview; uint8_t flags; };
 
-  // `set_delta(ctx)` uploads the caller's delta frame; it runs (in the leader) only when
-  // the context holds a different one.  `take(result)` copies the caller's planes out.
+  // `set_delta(ctx)` uploads the caller's delta frame (false: it failed); it runs (in the
+  // leader) only when the context holds a different one.  `take(result)` copies the caller's
+  // planes out.  Returns false when the batch failed on the GPU (latched by the leader; every
+  // member of the batch gets false, nobody's `take` runs).
   template <class SetDelta, class Take>
-  void Run(const uint16_t* pixels, uint64_t delta_id, SetDelta set_delta, Take take) {
+  bool Run(const uint16_t* pixels, uint64_t delta_id, SetDelta set_delta, Take take) {
+    if (!ctx_) return false;  // the context could not be created (latched then)
     std::unique_lock<std::mutex> l(m_);
     Batch* b = nullptr;
     for (;;) {
@@ -150,7 +190,14 @@ class PredictCombiner {
     }
     const uint32_t idx = b->joined++;
     l.unlock();
-    memcpy(fpvhip_stage_in(ctx_, (uint32_t)b->slot, idx), pixels, npix_ * 2);
+    if (uint16_t* dst = fpvhip_stage_in(ctx_, (uint32_t)b->slot, idx)) {
+      memcpy(dst, pixels, npix_ * 2);
+    } else {
+      FrameFail("fpvhip_stage_in", fpvhip_last_error(ctx_));
+      l.lock();
+      b->failed = bad_ = true;
+      l.unlock();
+    }
     l.lock();
     b->staged++;
     if (idx == 0) {  // leader
@@ -160,15 +207,19 @@ class PredictCombiner {
       cv_.notify_all();
       cv_.wait(l, [&] { return b->staged == b->joined; });
       const uint32_t n = b->joined;
+      bool ok = !b->failed;
       l.unlock();
-      if (ctx_delta_ != delta_id) {  // only the leader of the batch in flight touches the context
-        if (delta_id) set_delta(ctx_);
-        ctx_delta_ = delta_id;
+      if (ok && ctx_delta_ != delta_id) {  // only the leader of the batch in flight touches the context
+        ctx_delta_ = 0;
+        if (delta_id) ok = set_delta(ctx_);
+        if (ok) ctx_delta_ = delta_id;
       }
-      Check(fpvhip_predict_submit(ctx_, (uint32_t)b->slot, n, delta_id ? 1 : 0), ctx_, "fpvhip_predict_submit");
-      Check(fpvhip_predict_wait(ctx_, (uint32_t)b->slot, &b->high, &b->low, &b->preview, &b->flags), ctx_,
-            "fpvhip_predict_wait");
+      if (ok && fpvhip_predict_submit(ctx_, (uint32_t)b->slot, n, delta_id ? 1 : 0))
+        ok = FrameFail("fpvhip_predict_submit", fpvhip_last_error(ctx_));
+      if (ok && fpvhip_predict_wait(ctx_, (uint32_t)b->slot, &b->high, &b->low, &b->preview, &b->flags))
+        ok = FrameFail("fpvhip_predict_wait", fpvhip_last_error(ctx_));
       l.lock();
+      if (!ok) b->failed = bad_ = true;
       b->done = true;
       inflight_ = false;
       cv_.notify_all();
@@ -176,19 +227,23 @@ class PredictCombiner {
       cv_.notify_all();
       cv_.wait(l, [&] { return b->done; });
     }
+    const bool ok = !b->failed;
     l.unlock();
-    Result r;
-    r.high = b->high + (size_t)idx * npix_;
-    r.low = b->low + (size_t)idx * npix_;
-    r.preview = b->preview + (size_t)idx * npv_;
-    r.flags = b->flags[idx];
-    take(r);
+    if (ok) {
+      Result r;
+      r.high = b->high + (size_t)idx * npix_;
+      r.low = b->low + (size_t)idx * npix_;
+      r.preview = b->preview + (size_t)idx * npv_;
+      r.flags = b->flags[idx];
+      take(r);
+    }
     l.lock();
     if (++b->left == b->joined) {
       slot_free_[b->slot] = true;
       delete b;
       cv_.notify_all();
     }
+    return ok;
   }
 
  private:
@@ -196,7 +251,7 @@ class PredictCombiner {
     int slot = 0;
     uint64_t delta = 0;
     uint32_t joined = 0, staged = 0, left = 0;
-    bool done = false;
+    bool done = false, failed = false;
     const uint8_t *high = nullptr, *low = nullptr, *preview = nullptr, *flags = nullptr;
   };
   explicit PredictCombiner(const Key& k)
@@ -204,11 +259,12 @@ class PredictCombiner {
         max_batch_(BatchFor(std::get<1>(k) * std::get<2>(k))) {
     ctx_ = AcquireEncoderCtx(std::get<0>(k), (uint32_t)std::get<1>(k), (uint32_t)std::get<2>(k), std::get<3>(k),
                              std::get<4>(k), max_batch_, kSlots);
-    if (!ctx_) Fatal("Frame: fpvhip_create", fpvhip_last_error(nullptr));
+    if (!ctx_) FrameFail("Frame: fpvhip_create", fpvhip_last_error(nullptr));
   }
   std::mutex m_;
   std::condition_variable cv_;
   fpvhip_ctx* ctx_ = nullptr;
+  bool bad_ = false;  // the context saw a failure: destroyed, not cached, when the combiner goes
   size_t npix_, npv_;
   uint32_t max_batch_;
   std::atomic<int64_t> last_used_ms_{0};
@@ -219,6 +275,9 @@ class PredictCombiner {
 };
 constexpr uint32_t PredictCombiner::kMaxBatchCap;
 }  // namespace
+
+std::string Frame::LastError() { return FrameErrorLatch().text(); }
+void Frame::ClearError() { FrameErrorLatch().Reset(); }
 
 size_t Frame::MaxCompressedPlaneSize(size_t xsize, size_t ysize) {
   return BrotliEncoderMaxCompressedSize(xsize * ysize);
@@ -247,14 +306,17 @@ void Frame::SplitNow() const {
   std::lock_guard<std::mutex> l(SplitLock(this));
   if (!PlanesPending()) return;
   Frame* self = const_cast<Frame*>(this);
-  Fwd f(xsize_, ysize_, shift_, big_endian_);
+  // (after a latched failure the planes come out as zeros of the right size: callers index them)
   self->high_.resize(size_);
   if (shift_ != 8) self->low_.resize(size_);
   int no_low = 0;
-  Check(fpvhip_split_frame(f.ctx, pixels_->data(), self->high_.data(), shift_ != 8 ? self->low_.data() : nullptr,
-                           &no_low),
-        f.ctx, "fpvhip_split_frame");
-  if (no_low) self->flags_ |= FrameFlags::NO_LOW_BYTES;
+  if (!FrameFailed()) {
+    Fwd f(xsize_, ysize_, shift_, big_endian_);
+    if (f.ctx && f.Check(fpvhip_split_frame(f.ctx, pixels_->data(), self->high_.data(),
+                                            shift_ != 8 ? self->low_.data() : nullptr, &no_low), "fpvhip_split_frame") &&
+        no_low)
+      self->flags_ |= FrameFlags::NO_LOW_BYTES;
+  }
   __atomic_store_n(&planes_pending_, 0, __ATOMIC_RELEASE);
 }
 
@@ -315,20 +377,22 @@ void Frame::Predict(Frame& delta_frame) {
     if (!want_delta || (state_ & FrameState::DELTA_PREDICTED)) return;  // nothing left to do
   }
   if ((state_ & (predicted | FrameState::COMPRESSED)) || size_ == 0 || (!PlanesPending() && high_.size() != size_))
-    Fatal("Frame::Predict", "only frames in the RAW state can be predicted on the GPU");
+    Fatal("Frame::Predict", "only frames in the RAW state can be predicted on the GPU");  // API misuse, not a GPU failure
+  if (FrameFailed()) return;  // latched: the frame stays as it is (Frame::LastError)
   const bool with_delta = delta_frame.state() > FrameState::EMPTY;
   const size_t npv = (xsize_ / 4) * (ysize_ / 4);
   if (pixels_) {
     // the fused pass over the pixels, in one batch with whatever other threads are asking for
-    auto set_delta = [&](fpvhip_ctx* ctx) {
+    auto set_delta = [&](fpvhip_ctx* ctx) -> bool {
       if (delta_frame.pixels_ && delta_frame.shift_ == shift_ && delta_frame.big_endian_ == big_endian_) {
-        Check(fpvhip_set_delta_raw(ctx, delta_frame.pixels_->data()), ctx, "fpvhip_set_delta_raw");
+        if (fpvhip_set_delta_raw(ctx, delta_frame.pixels_->data())) return FrameFail("fpvhip_set_delta_raw", fpvhip_last_error(ctx));
       } else {
         if (delta_frame.PlanesPending()) delta_frame.SplitNow();
-        Check(fpvhip_set_delta_planes(ctx, delta_frame.high_.data(),
-                                      delta_frame.low_.size() == size_ ? delta_frame.low_.data() : nullptr),
-              ctx, "fpvhip_set_delta_planes");
+        if (fpvhip_set_delta_planes(ctx, delta_frame.high_.data(),
+                                    delta_frame.low_.size() == size_ ? delta_frame.low_.data() : nullptr))
+          return FrameFail("fpvhip_set_delta_planes", fpvhip_last_error(ctx));
       }
+      return !FrameFailed();
     };
     auto take = [&](const PredictCombiner::Result& r) {
       high_.assign(r.high, r.high + size_);
@@ -336,23 +400,31 @@ void Frame::Predict(Frame& delta_frame) {
       preview_.assign(r.preview, r.preview + npv);
       flags_ = (uint8_t)(r.flags & (FrameFlags::USE_DELTA | FrameFlags::USE_CG | FrameFlags::NO_LOW_BYTES));
     };
-    PredictCombiner::Get(PredictCombiner::Key(FrameDevice(), xsize_, ysize_, shift_, big_endian_))
-        ->Run(pixels_->data(), with_delta ? delta_frame.content_id_ : 0, set_delta, take);
+    const int dev = FrameDevice();
+    if (dev < 0) return;
+    if (!PredictCombiner::Get(PredictCombiner::Key(dev, xsize_, ysize_, shift_, big_endian_))
+             ->Run(pixels_->data(), with_delta ? delta_frame.content_id_ : 0, set_delta, take))
+      return;  // latched; the frame keeps its pixels and stays RAW
     planes_pending_ = 0;
   } else {
     // planes only (8-bit constructor, or a frame that went through Uncompress)
     if (with_delta && delta_frame.PlanesPending()) delta_frame.SplitNow();
     Fwd f(xsize_, ysize_, 0, false);
+    if (!f.ctx) return;
     const uint8_t *gh, *gl, *gp, *gf;
-    if (with_delta)
-      Check(fpvhip_set_delta_planes(f.ctx, delta_frame.high_.data(),
-                                    delta_frame.low_.size() == size_ ? delta_frame.low_.data() : nullptr),
-            f.ctx, "fpvhip_set_delta_planes");
-    memcpy(fpvhip_stage_plane(f.ctx, 0, 0, 0), high_.data(), size_);
-    if (low_.size() == size_) memcpy(fpvhip_stage_plane(f.ctx, 0, 0, 1), low_.data(), size_);
-    else memset(fpvhip_stage_plane(f.ctx, 0, 0, 1), 0, size_);
-    Check(fpvhip_predict_planes_submit(f.ctx, 0, 1, with_delta), f.ctx, "fpvhip_predict_planes_submit");
-    Check(fpvhip_predict_wait(f.ctx, 0, &gh, &gl, &gp, &gf), f.ctx, "fpvhip_predict_wait");
+    if (with_delta &&
+        !f.Check(fpvhip_set_delta_planes(f.ctx, delta_frame.high_.data(),
+                                         delta_frame.low_.size() == size_ ? delta_frame.low_.data() : nullptr),
+                 "fpvhip_set_delta_planes"))
+      return;
+    uint8_t *sh = fpvhip_stage_plane(f.ctx, 0, 0, 0), *sl = fpvhip_stage_plane(f.ctx, 0, 0, 1);
+    if (!sh || !sl) { f.Check(-1, "fpvhip_stage_plane"); return; }
+    memcpy(sh, high_.data(), size_);
+    if (low_.size() == size_) memcpy(sl, low_.data(), size_);
+    else memset(sl, 0, size_);
+    if (!f.Check(fpvhip_predict_planes_submit(f.ctx, 0, 1, with_delta), "fpvhip_predict_planes_submit") ||
+        !f.Check(fpvhip_predict_wait(f.ctx, 0, &gh, &gl, &gp, &gf), "fpvhip_predict_wait"))
+      return;
     memcpy(high_.data(), gh, size_);
     if (low_.size() == size_) memcpy(low_.data(), gl, size_);
     preview_.assign(gp, gp + npv);
@@ -370,19 +442,20 @@ void Frame::Predict(Frame& delta_frame) {
 void Frame::Compress(Frame& delta_frame) {
   if (state_ & FrameState::COMPRESSED) return;
   Predict(delta_frame);
+  if (!(state_ & FrameState::CG_PREDICTED)) return;  // a latched GPU failure: nothing to compress (Frame::LastError)
   std::vector<uint8_t> out;
-  if (!BrotliAppend(high_.data(), size_, &out)) Fatal("Brotli", "high plane");
+  if (!BrotliAppend(high_.data(), size_, &out)) { FrameFail("Brotli", "high plane"); return; }
   high_.swap(out);
   if (flags_ & FrameFlags::NO_LOW_BYTES) {
     low_.clear();
   } else {
     out.clear();
-    if (!BrotliAppend(low_.data(), size_, &out)) Fatal("Brotli", "low plane");
+    if (!BrotliAppend(low_.data(), size_, &out)) { FrameFail("Brotli", "low plane"); return; }
     low_.swap(out);
   }
   if (state_ & FrameState::PREVIEW_GENERATED) {
     out.clear();
-    if (!BrotliAppend(preview_.data(), preview_.size(), &out)) Fatal("Brotli", "preview");
+    if (!BrotliAppend(preview_.data(), preview_.size(), &out)) { FrameFail("Brotli", "preview"); return; }
     preview_.swap(out);
   }
   state_ &= ~FrameState::RAW;
@@ -444,19 +517,25 @@ void Frame::Uncompress(Frame& delta_frame) {
   const bool undo_delta = (state_ & FrameState::DELTA_PREDICTED) && (flags_ & FrameFlags::USE_DELTA) &&
                           delta_frame.state() != FrameState::EMPTY;
   const bool planes_ok = high_.size() == size_ && size_ > 0;
+  if (FrameFailed() && (undo_cg || undo_delta)) return;  // latched: the predictions stay applied, the state says so
   if (planes_ok && (undo_cg || undo_delta)) {
     Inv v(xsize_, ysize_);
-    if (undo_delta)
-      Check(fpvhip_set_delta_planes(v.ctx, delta_frame.high_.data(),
-                                    delta_frame.low_.size() == size_ ? delta_frame.low_.data() : nullptr),
-            v.ctx, "fpvhip_set_delta_planes");
+    if (!v.ctx) return;
+    if (undo_delta &&
+        !v.Check(fpvhip_set_delta_planes(v.ctx, delta_frame.high_.data(),
+                                         delta_frame.low_.size() == size_ ? delta_frame.low_.data() : nullptr),
+                 "fpvhip_set_delta_planes"))
+      return;
     const bool has_low = low_.size() == size_;
-    memcpy(fpvhip_stage_plane(v.ctx, 0, 0, 0), high_.data(), size_);
-    if (has_low) memcpy(fpvhip_stage_plane(v.ctx, 0, 0, 1), low_.data(), size_);
+    uint8_t *sh = fpvhip_stage_plane(v.ctx, 0, 0, 0), *sl = fpvhip_stage_plane(v.ctx, 0, 0, 1);
+    if (!sh || !sl) { v.Check(-1, "fpvhip_stage_plane"); return; }
+    memcpy(sh, high_.data(), size_);
+    if (has_low) memcpy(sl, low_.data(), size_);
     const uint8_t f = (uint8_t)((undo_delta ? 1 : 0) | (undo_cg ? 2 : 0) | (has_low ? 0 : 4));
-    Check(fpvhip_inverse_planes_submit(v.ctx, 0, 1, &f), v.ctx, "fpvhip_inverse_planes_submit");
     const uint8_t *gh, *gl;
-    Check(fpvhip_predict_wait(v.ctx, 0, &gh, &gl, nullptr, nullptr), v.ctx, "fpvhip_predict_wait");
+    if (!v.Check(fpvhip_inverse_planes_submit(v.ctx, 0, 1, &f), "fpvhip_inverse_planes_submit") ||
+        !v.Check(fpvhip_predict_wait(v.ctx, 0, &gh, &gl, nullptr, nullptr), "fpvhip_predict_wait"))
+      return;
     memcpy(high_.data(), gh, size_);
     if (has_low) memcpy(low_.data(), gl, size_);
   }
@@ -465,19 +544,24 @@ void Frame::Uncompress(Frame& delta_frame) {
     if ((state_ & FrameState::PREVIEW_GENERATED) && preview_.size() == size_ / 16 && pw && ph &&
         pw * ph == preview_.size()) {
       Inv v(pw, ph);
-      memcpy(fpvhip_stage_plane(v.ctx, 0, 0, 0), preview_.data(), preview_.size());
+      uint8_t* sp = v.ctx ? fpvhip_stage_plane(v.ctx, 0, 0, 0) : nullptr;
       const uint8_t f = 2 | 4;
-      if ((pw * ph) % 4 == 0) {
-        Check(fpvhip_inverse_planes_submit(v.ctx, 0, 1, &f), v.ctx, "fpvhip_inverse_planes_submit");
+      if (!sp) {
+        if (v.ctx) v.Check(-1, "fpvhip_stage_plane");
+      } else if ((pw * ph) % 4 == 0) {
+        memcpy(sp, preview_.data(), preview_.size());
         const uint8_t* gh;
-        Check(fpvhip_predict_wait(v.ctx, 0, &gh, nullptr, nullptr, nullptr), v.ctx, "fpvhip_predict_wait");
-        memcpy(preview_.data(), gh, preview_.size());
+        if (v.Check(fpvhip_inverse_planes_submit(v.ctx, 0, 1, &f), "fpvhip_inverse_planes_submit") &&
+            v.Check(fpvhip_predict_wait(v.ctx, 0, &gh, nullptr, nullptr, nullptr), "fpvhip_predict_wait"))
+          memcpy(preview_.data(), gh, preview_.size());
       } else {  // odd preview size: pixels out, keep the high bytes
-        Check(fpvhip_inverse_submit(v.ctx, 0, 1, &f), v.ctx, "fpvhip_inverse_submit");
+        memcpy(sp, preview_.data(), preview_.size());
         const uint16_t* px;
-        Check(fpvhip_inverse_wait(v.ctx, 0, &px), v.ctx, "fpvhip_inverse_wait");
-        for (size_t i = 0; i < preview_.size(); i++) preview_[i] = (uint8_t)(px[i] >> 8);
+        if (v.Check(fpvhip_inverse_submit(v.ctx, 0, 1, &f), "fpvhip_inverse_submit") &&
+            v.Check(fpvhip_inverse_wait(v.ctx, 0, &px), "fpvhip_inverse_wait"))
+          for (size_t i = 0; i < preview_.size(); i++) preview_[i] = (uint8_t)(px[i] >> 8);
       }
+      if (FrameFailed()) return;  // the planes are back, the preview is not: leave the state as it is
     }
     flags_ &= ~FrameFlags::USE_CG;
     state_ &= ~FrameState::CG_PREDICTED;

@@ -58,6 +58,31 @@ void Fatal(const char* what, const char* detail) {
   abort();
 }
 
+bool ErrorLatch::Fail(const char* who, const char* what, const char* detail) {
+  if (getenv("FPV_ABORT_ON_ERROR")) Fatal(what, detail);
+  std::lock_guard<std::mutex> l(m_);
+  if (!failed_.load()) {
+    text_ = std::string(what) + ": " + (detail ? detail : "");
+    fprintf(stderr, "fpv-mi355x: %s failed: %s (no CPU fallback exists; further calls are no-ops until the error is "
+                    "cleared; FPV_ABORT_ON_ERROR=1 aborts instead)\n", who, text_.c_str());
+    failed_.store(true, std::memory_order_release);
+  }
+  return false;
+}
+std::string ErrorLatch::text() const {
+  std::lock_guard<std::mutex> l(m_);
+  return text_;
+}
+void ErrorLatch::Reset() {
+  std::lock_guard<std::mutex> l(m_);
+  text_.clear();
+  failed_.store(false, std::memory_order_release);
+}
+ErrorLatch& FrameErrorLatch() {
+  static ErrorLatch* l = new ErrorLatch();
+  return *l;
+}
+
 // -------------------------------------------------------------- LE helpers --
 
 uint32_t Load32(const uint8_t* p) {

@@ -5,10 +5,12 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <condition_variable>
 #include <functional>
 #include <memory>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "fpv_hip.h"
@@ -19,6 +21,24 @@ namespace internal {
 bool Failure(const char* file, int line, const char* msg);
 #define FPV_FAILURE(msg) ::fpvc::internal::Failure(__FILE__, __LINE__, msg)
 [[noreturn]] void Fatal(const char* what, const char* detail);
+
+// First failure of an adapter object (or of the process-wide Frame API): kept and printed once;
+// the reference never aborts (cc:160-181: FAILURE returns false), so neither do the adapters.
+// FPV_ABORT_ON_ERROR=1 aborts at the failure instead (rounds 1-3's behaviour).
+class ErrorLatch {
+ public:
+  // Latches `who: what: detail` if nothing is latched yet.  Returns false (for `return latch.Fail(..)`).
+  bool Fail(const char* who, const char* what, const char* detail);
+  bool failed() const { return failed_.load(std::memory_order_acquire); }
+  std::string text() const;
+  void Reset();
+
+ private:
+  mutable std::mutex m_;
+  std::atomic<bool> failed_{false};
+  std::string text_;
+};
+ErrorLatch& FrameErrorLatch();  // the Frame API's (process-wide: frames are values, they own no session)
 
 uint32_t Load32(const uint8_t* p);
 uint64_t Load64(const uint8_t* p);

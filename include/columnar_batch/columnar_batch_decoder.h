@@ -6,6 +6,7 @@
 
 #include <future>
 #include <memory>
+#include <string>
 
 #include "../fusion_power_video.h"
 #include "columnar_batch.h"
@@ -25,6 +26,10 @@ class ColumnarBatchDecoder {
   std::future<BatchPtr> PushBatch(BatchPtr batch);
   // The future yields the latest timestamp handed to the image processor.
   std::shared_future<int64_t> Close();
+  // Extension (not upstream): the decoder's first failure ("" while there is none).  The batch
+  // that hit it gets it through its future (an exception), later PushBatch calls return an
+  // invalid future; nothing aborts.
+  std::string LastError() const;
 
  private:
   struct Impl;

@@ -7,6 +7,7 @@
 
 #include <future>
 #include <memory>
+#include <string>
 
 #include "../fusion_power_video.h"
 #include "columnar_batch.h"
@@ -30,6 +31,10 @@ class ColumnarBatchEncoder {
   void ReturnProcessedBatch(BatchPtr processed);
   // Flushes; the future yields the timestamp of the last frame stored (-1: none).
   std::shared_future<int64_t> Close();
+  // Extension (not upstream): the encoder's first GPU failure ("" while there is none).  The
+  // PushFrame call that hit it gets a future carrying it as an exception, later calls an invalid
+  // future (as after Close); batches in flight are dropped; nothing aborts.
+  std::string LastError() const;
 
  private:
   struct Impl;

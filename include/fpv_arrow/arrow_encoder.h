@@ -22,6 +22,7 @@
 #include <functional>
 #include <future>
 #include <memory>
+#include <string>
 
 #include "../fusion_power_video.h"
 
@@ -42,6 +43,11 @@ class ArrowEncoder {
   std::future<void*> PushFrame(uint64_t timestamp, uint16_t* frame, void* info);
   // Flushes; the future yields the timestamp of the last frame stored (-1: none).
   std::shared_future<int64_t> Close();
+  // Extension (not upstream): the first failure of this encoder -- a GPU failure of its columnar
+  // encoder or a record batch that could not be built -- or "".  The PushFrame call that hits a
+  // GPU failure gets it through its future (an exception), later calls an invalid future;
+  // nothing aborts.
+  std::string LastError() const;
 
  private:
   struct Impl;

@@ -25,6 +25,7 @@
 #include <mutex>
 #include <queue>
 #include <thread>
+#include <string>
 #include <vector>
 
 namespace fpvc {
@@ -111,6 +112,15 @@ class Frame {
                          uint8_t* encoded_preview_buffer, bool parallel = true);
   void OutputCore(std::vector<uint8_t>* out);
   void OutputFull(std::vector<uint8_t>* out);
+
+  // Extension (not in the upstream header): the first GPU failure of the Frame API in this
+  // process ("" while there is none).  Every method above is void, as upstream (h:75-139), and
+  // the reference never aborts: the method that hits a failure leaves its frame as it found it
+  // (Predict: still RAW; Compress: not COMPRESSED; Uncompress: predictions still applied, the
+  // state bits say so), and later GPU-touching methods are no-ops until ClearError().
+  // FPV_ABORT_ON_ERROR=1 aborts at the failure instead.
+  static std::string LastError();
+  static void ClearError();
 
  protected:
   std::vector<uint8_t> preview_;

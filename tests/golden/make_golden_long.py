@@ -5,7 +5,10 @@ oracle/Makefile) on the cycled synthetic frames.  Only data (hashes, sizes) is s
 
   config 1 at its stated size: 1000 frames 1280x800 12-bit plasma, 64 distinct frames cycled.
   config 3 at its stated size: 1000 frames 4096x4096 16-bit plasma, 8 distinct frames cycled
-  (`python make_golden_long.py config3`: about a minute of reference CPU time on 8 cores)."""
+  (`python make_golden_long.py config3`: about a minute of reference CPU time on 8 cores).
+  config 2 at its stated size: 10 000 frames 1920x1080 16-bit plasma, 32 distinct frames cycled
+  (`python make_golden_long.py config2`: 29.7 GB of stream hashed as it leaves the reference's
+  encode.cc; the frame index at its end holds 64-bit offsets beyond 2^32, cc:1185-1197)."""
 import hashlib, importlib, json, os, subprocess, sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -38,6 +41,16 @@ def ref_stream_sha(frames, total, xs, ys, shift, threads=8):
 
 def main():
     man = json.load(open(os.path.join(HERE, "manifest.json")))
+    if "config2" in sys.argv[1:]:
+        fr = synth.plasma_frames(32, 1920, 1080, bits=16, seed=9)
+        sha, size = ref_stream_sha(fr, 10000, 1920, 1080, 0)
+        man["workloads"]["plasma16_1920x1080x10000_cycled32_seed9"] = {
+            "xs": 1920, "ys": 1080, "shift": 0, "big_endian": False, "frames": 10000, "distinct": 32,
+            "note": "frame i = synth.plasma_frames(32, 1920, 1080, bits=16, seed=9)[i % 32]; delta frame = frame 0 (encode.cc:87-90)",
+            "fpv_sha256": sha, "fpv_size": size, "generator": "tests/golden/make_golden_long.py config2"}
+        json.dump(man, open(os.path.join(HERE, "manifest.json"), "w"), indent=1)
+        print(sha, size)
+        return
     if "config3" in sys.argv[1:]:
         fr = synth.plasma_frames(8, 4096, 4096, bits=16, seed=11)
         sha, size = ref_stream_sha(fr, 1000, 4096, 4096, 0)

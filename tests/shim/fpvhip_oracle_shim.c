@@ -24,11 +24,14 @@
  *                             (a slow GPU); fpvhip_shim_overlapped_waits() counts the waits of
  *                             OTHER devices that returned while such a sleep was in progress
  *   FPV_SHIM_FAIL_WAIT=<k>    the k-th fpvhip_predict_wait made while the variable is set (1-based) fails
+ *   FPV_SHIM_FAIL_SUBMIT=<k>  the k-th fpvhip_predict_submit / fpvhip_predict_planes_submit made while it is set fails
+ *   FPV_SHIM_FAIL_INVERSE=<k> the k-th inverse submit (pixels, raw or planes) made while it is set fails
  * Bookkeeping the tests read back:
  *   fpvhip_shim_warmups(dev)      fpvhip_warmup calls seen for the device
  *   fpvhip_shim_cold_creates()    contexts created on a device that had not been warmed yet */
 static int g_delayed_active, g_overlapped, g_waits;
-static int g_warmups[64], g_cold_creates;
+static int g_warmups[64], g_cold_creates, g_submits, g_inverses;
+
 int fpvhip_shim_overlapped_waits(void) { return __atomic_load_n(&g_overlapped, __ATOMIC_SEQ_CST); }
 int fpvhip_shim_warmups(int device) { return __atomic_load_n(&g_warmups[device & 63], __ATOMIC_SEQ_CST); }
 int fpvhip_shim_cold_creates(void) { return __atomic_load_n(&g_cold_creates, __ATOMIC_SEQ_CST); }
@@ -53,6 +56,18 @@ struct fpvhip_ctx {
 };
 
 static char g_err[128];
+static int injected(const char *var, int *counter, fpvhip_ctx *c) {  /* counts calls made while `var` is set */
+  const char *e = getenv(var);
+  if (!e) {
+    __atomic_store_n(counter, 0, __ATOMIC_SEQ_CST);
+    return 0;
+  }
+  if (__atomic_add_fetch(counter, 1, __ATOMIC_SEQ_CST) == atoi(e)) {
+    snprintf(c->err, sizeof c->err, "injected failure (%s)", var);
+    return 1;
+  }
+  return 0;
+}
 
 int fpvhip_abi_version(void) { return FPVHIP_ABI_VERSION; }
 int fpvhip_device_count(void) {
@@ -159,7 +174,9 @@ uint16_t *fpvhip_stage_in(fpvhip_ctx *c, uint32_t slot, uint32_t k) {
 int fpvhip_predict_submit(fpvhip_ctx *c, uint32_t slot, uint32_t n, int with_delta) {
   slot_t *s = &c->slots[slot];
   uint32_t k;
-  uint8_t *pv = (uint8_t *)malloc(c->npix / 16 + c->npv + 16);
+  uint8_t *pv;
+  if (injected("FPV_SHIM_FAIL_SUBMIT", &g_submits, c)) return -1;
+  pv = (uint8_t *)malloc(c->npix / 16 + c->npv + 16);
   if (!c->fwd_ok || (with_delta && !c->have_delta)) {
     snprintf(c->err, sizeof c->err, "bad predict_submit");
     free(pv);
@@ -180,10 +197,7 @@ int fpvhip_predict_wait(fpvhip_ctx *c, uint32_t slot, const uint8_t **high,
   slot_t *s = &c->slots[slot];
   const char *e;
   int delayed = 0;
-  if ((e = getenv("FPV_SHIM_FAIL_WAIT")) && __atomic_add_fetch(&g_waits, 1, __ATOMIC_SEQ_CST) == atoi(e)) {
-    snprintf(c->err, sizeof c->err, "injected failure of fpvhip_predict_wait (FPV_SHIM_FAIL_WAIT)");
-    return -1;
-  }
+  if (injected("FPV_SHIM_FAIL_WAIT", &g_waits, c)) return -1;
   if ((e = getenv("FPV_SHIM_DELAY")) && atoi(e) == c->device && strchr(e, ':')) {
     struct timespec ts;
     const long ms = atol(strchr(e, ':') + 1);
@@ -218,6 +232,7 @@ uint8_t *fpvhip_stage_plane(fpvhip_ctx *c, uint32_t slot, uint32_t k, int which)
 int fpvhip_inverse_submit(fpvhip_ctx *c, uint32_t slot, uint32_t n, const uint8_t *flags) {
   slot_t *s = &c->slots[slot];
   uint32_t k;
+  if (injected("FPV_SHIM_FAIL_INVERSE", &g_inverses, c)) return -1;
   for (k = 0; k < n; k++) {
     if ((flags[k] & 1) && !c->have_delta) {
       snprintf(c->err, sizeof c->err, "delta frame not given");
@@ -246,6 +261,7 @@ int fpvhip_inverse_planes_submit(fpvhip_ctx *c, uint32_t slot, uint32_t n, const
   slot_t *s = &c->slots[slot];
   uint32_t k;
   size_t i;
+  if (injected("FPV_SHIM_FAIL_INVERSE", &g_inverses, c)) return -1;
   for (k = 0; k < n; k++) {
     uint8_t *h = s->high + (size_t)k * c->npix, *l = s->low + (size_t)k * c->npix;
     if ((flags[k] & 1) && !c->have_delta) { snprintf(c->err, sizeof c->err, "delta frame not given"); return -1; }

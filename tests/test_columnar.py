@@ -103,3 +103,25 @@ def test_columnar_format_matches_reference_over_cpu_shim():
 @pytest.mark.gpu
 def test_columnar_format_matches_reference_on_gpu():
     _columnar_parity(os.path.join(BIN, "columnar_dump"))
+
+
+def test_adapter_gpu_failures_are_latched_not_fatal():
+    """Frame API, ColumnarBatchEncoder and ColumnarBatchDecoder with injected GPU failures (the CPU
+    shim's FPV_SHIM_FAIL_* knobs: a failing fpvhip_predict_submit / _wait / inverse submit): nothing
+    aborts; the failing call reports through the channel its signature has (the futures of the
+    columnar classes carry an exception; Frame's void methods latch Frame::LastError and leave the
+    frame as it was), later calls are refused / no-ops, Close still answers, and after
+    Frame::ClearError() -- or with a fresh encoder / decoder object -- the same work gives the
+    same bytes (tests/adapter_fail_driver.cc).  Reference convention: cc:160-181."""
+    exe = os.path.join(ROOT, "tests", "shim", "adapter_fail_cpushim")
+    if not os.path.exists(exe):
+        pytest.skip("tests/shim/adapter_fail_cpushim not built (make columnar)")
+    env = dict(os.environ)
+    env.pop("FPV_ABORT_ON_ERROR", None)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "adapter failures ok" in r.stdout, r.stdout + r.stderr[-3000:]
+    for who in ("Frame API failed", "ColumnarBatchEncoder failed", "ColumnarBatchDecoder failed"):
+        assert who in r.stderr, who
+    # FPV_ABORT_ON_ERROR=1 keeps the old behaviour
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=dict(env, FPV_ABORT_ON_ERROR="1"))
+    assert r.returncode != 0 and "fatal" in r.stderr

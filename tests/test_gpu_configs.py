@@ -4,7 +4,8 @@ config 1: the 1000-frame 1280x800 stream, SHA-256 against the manifest made by t
           reference (tests/golden/make_golden_long.py).
 config 2: the 10 000-frame 1920x1080 16-bit stream through Encoder -> StreamingDecoder with bounded
           memory: every decoded frame == input, the frame index (64-bit offsets, 29.7 GB of
-          stream) checked entry by entry, its last offset asserted.
+          stream) checked entry by entry, its last offset asserted; and the whole stream's SHA-256
+          against the REAL reference's (make_golden_long.py config2).
 config 3: 1000 frames 4096x4096 16-bit through the Encoder over two contexts (FPV_DEVICES=0,0:
           the batch round-robin of the multi-GPU path on the one GPU of the box), SHA-256 against
           the manifest made by the REAL reference (make_golden_long.py config3).
@@ -88,6 +89,22 @@ def test_config2_10000_frame_stream_bounded_memory(synth):
     assert r.returncode == 0 and r.stdout.startswith("ok stream 10000 frames"), r.stdout + r.stderr
     assert "last index offset 29712630910 (> 2^32)" in r.stdout, r.stdout
     _log("config2 " + r.stdout.strip())
+
+
+def test_config2_10000_frame_stream_sha256(synth):
+    """BASELINE config 2 at its count, byte for byte: the 29.7 GB stream of 10 000 frames 1920x1080
+    16-bit (its frame index holds 64-bit offsets beyond 2^32, cc:1185-1197) hashed as it leaves the
+    Encoder, against the SHA-256 of what the REAL reference's encode.cc wrote for the same frames
+    in the build container (tests/golden/make_golden_long.py config2)."""
+    man = json.load(open(os.path.join(ROOT, "tests", "golden", "manifest.json")))["workloads"].get("plasma16_1920x1080x10000_cycled32_seed9")
+    assert man, "manifest entry missing: run tests/golden/make_golden_long.py config2 in the build container"
+    with tempfile.TemporaryDirectory(dir="/tmp") as d:
+        p = os.path.join(d, "plasma16.raw")
+        synth.plasma_frames(32, 1920, 1080, bits=16, seed=9).tofile(p)
+        sha, size, dt = _sha_of_encode([p, 1920, 1080, 0, 32, 10000, _threads()])
+    assert size == man["fpv_size"]
+    assert sha == man["fpv_sha256"]
+    _log(f"ok config2 10000 frames 1920x1080: {size} bytes, sha256 {sha} == reference, {dt:.1f} s")
 
 
 def test_config3_1000_frames_4096x4096_two_contexts_sha256(synth):

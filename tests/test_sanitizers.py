@@ -21,3 +21,4 @@ def test_threadsanitizer_host_pipeline():
     assert "eight devices, one slow: ok" in r.stdout                 # one dispatcher thread per device
     assert "latched GPU failure: ok" in r.stdout                     # Encoder::LastError instead of abort()
     assert r.stdout.count("columnar ok") == 5   # the columnar adapter's queues and futures
+    assert "adapter failures ok" in r.stdout    # latched GPU failures in the Frame API / columnar adapters (futures carrying exceptions)

@@ -43,7 +43,11 @@ $(LIBDIR)/libfpv_amd.so: $(HOST_SRC) $(HOST_HDR) $(LIBDIR)/libfpvhip.so
 
 # Our own CLI tools (written from scratch; usable on the GPU box) and the native test driver
 # of the BASELINE configurations at their stated frame counts.
-tools: $(BINDIR)/fpv_encode $(BINDIR)/fpv_decode $(BINDIR)/fpv_benchmark $(BINDIR)/configs_driver $(BINDIR)/frame_rate
+tools: $(BINDIR)/fpv_encode $(BINDIR)/fpv_decode $(BINDIR)/fpv_benchmark $(BINDIR)/configs_driver $(BINDIR)/frame_rate $(BINDIR)/cold_probe
+# what any fresh process pays for its first GPU milliseconds (tests/test_gpu_cli.py: the floor of a cold start)
+$(BINDIR)/cold_probe: tools/exp/cold_probe.hip
+	@mkdir -p $(BINDIR)
+	$(HIPCC) --offload-arch=$(ARCH) -O2 -w $< -pthread -o $@
 $(BINDIR)/configs_driver: tests/configs_driver.cc $(LIBDIR)/libfpv_amd.so
 	@mkdir -p $(BINDIR)
 	$(CXX) $(CXXFLAGS) $< -L$(LIBDIR) -lfpv_amd -lfpvhip \

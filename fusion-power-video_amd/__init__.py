@@ -79,6 +79,9 @@ def _declare_hip(lib):
     lib.fpvhip_debug_counters.argtypes = [vp, c.POINTER(c.c_uint32), u32]
     lib.fpvhip_inverse_pass_stats.restype = i32
     lib.fpvhip_inverse_pass_stats.argtypes = [vp, c.POINTER(c.c_uint32), i32]
+    if hasattr(lib, "fpvhip_debug_set_chain_mask"):
+        lib.fpvhip_debug_set_chain_mask.restype = i32
+        lib.fpvhip_debug_set_chain_mask.argtypes = [vp, u32]
     for name in ("fpvhip_set_delta_raw", "fpvhip_set_delta_decoded", "fpvhip_predict_submit",
                  "fpvhip_predict_wait", "fpvhip_inverse_submit", "fpvhip_inverse_wait",
                  "fpvhip_predict_device", "fpvhip_inverse_device"):
@@ -232,6 +235,10 @@ class Predictor:
         buf = (ctypes.c_uint32 * n)()
         self._check(self.lib.fpvhip_debug_counters(self.ctx, buf, n), "debug_counters")
         return [int(v) for v in buf]
+
+    def set_chain_mask(self, value):
+        """Overwrites the three-wave inverse kernel's per-CU "SIMD taken" words (0: all free)."""
+        self._check(self.lib.fpvhip_debug_set_chain_mask(self.ctx, value), "debug_set_chain_mask")
 
     def forward_kernel_names(self):
         """The three launches of one forward batch, in the order of time_predict(per_kernel=True)."""

@@ -751,6 +751,13 @@ double fpvhip_slot_elapsed_ms(fpvhip_ctx* c, uint32_t slot) {
   return ms;
 }
 
+int fpvhip_debug_set_chain_mask(fpvhip_ctx* c, uint32_t value) {
+  if (!c) return fail(nullptr, "null context");
+  HIPOK(c, hipSetDevice(c->device));
+  HIPOK(c, fpvhip::set_chain_simd_mask(value));
+  return 0;
+}
+
 const char* fpvhip_forward_kernel_names(fpvhip_ctx* c) {
   if (!c || !c->g.fwd_ok) return "";
   if (c->g.tile8_ok) return "k_tile8,k_frame8,k_redo8";

@@ -112,6 +112,9 @@ hipError_t launch_inverse(const Geom& g, const uint8_t* d_high,
                           uint32_t nframes, uint16_t* d_frames, hipStream_t s,
                           uint32_t* d_diag = nullptr);
 
+// Overwrites the per-CU "SIMDs running a chain wave" words of the three-wave inverse (current device).
+hipError_t set_chain_simd_mask(uint32_t value);
+
 // Name of the kernel launch_inverse picks for a batch of nframes (diagnostics, bench).
 const char* inverse_kernel_name(const Geom& g, uint32_t nframes);
 

@@ -26,6 +26,7 @@
 #include <algorithm>
 #include <mutex>
 #include <type_traits>
+#include <vector>
 
 namespace fpvhip {
 
@@ -2940,18 +2941,34 @@ static size_t trio_lds(const Geom& g, uint32_t k4, uint32_t mblk) {  // ring, 2 
 // Frames whose three-wave workgroups (k_inverse_trio<k4, mblk>) are all resident at the same
 // time on the current device: the runtime's occupancy answer for the instantiation times the CUs.
 static uint32_t trio_capacity(const Geom& g, uint32_t k4, uint32_t mblk) {
+  // The answer depends on the LDS bytes of the launch, i.e. on the frame width (the ring), not on
+  // (k4, mblk) alone: a second context with another width must not reuse the first one's figure.
+  struct Slot { uint32_t lds, cap; };
   static std::mutex m;
-  static uint32_t capm[64][kSpecMaxK4 + 1][5] = {};
+  static Slot capm[64][kSpecMaxK4 + 1][5][4] = {};  // a few widths per instantiation; beyond that the oldest entry is replaced
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) dev = 0;
   dev &= 63;
   if (k4 == 0 || k4 > kSpecMaxK4 || (mblk != 1 && mblk != 2 && mblk != 4)) return 0;
-  if (trio_lds(g, k4, mblk) > 64 * 1024) return 0;
+  const size_t lds = trio_lds(g, k4, mblk);
+  if (lds > 64 * 1024) return 0;
   std::lock_guard<std::mutex> l(m);
-  uint32_t* cap_slot = &capm[dev][k4][mblk];
+  Slot* slots = capm[dev][k4][mblk];
+  uint32_t* cap_slot = nullptr;
+  for (int i = 0; i < 4 && !cap_slot; i++)
+    if (slots[i].cap && slots[i].lds == (uint32_t)lds) cap_slot = &slots[i].cap;
+  if (!cap_slot) {
+    static uint32_t next_victim = 0;
+    Slot* sl = nullptr;
+    for (int i = 0; i < 4 && !sl; i++)
+      if (!slots[i].cap) sl = &slots[i];
+    if (!sl) sl = &slots[next_victim++ & 3];
+    sl->lds = (uint32_t)lds;
+    sl->cap = 0;
+    cap_slot = &sl->cap;
+  }
   if (!*cap_slot) {
     int blocks = 0;
-    const size_t lds = trio_lds(g, k4, mblk);
     hipError_t e = hipErrorInvalidValue;
 #define FPV_OCC(K4, MB) if (k4 == K4 && mblk == MB) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_inverse_trio<K4, MB>, 192, lds);
 #define FPV_OCC3(K4) FPV_OCC(K4, 1) FPV_OCC(K4, 2) FPV_OCC(K4, 4)
@@ -2998,6 +3015,13 @@ static int inverse_mode(const Geom& g, uint32_t nframes, uint32_t* k4, uint32_t*
     }
   }
   return mode;
+}
+
+hipError_t set_chain_simd_mask(uint32_t value) {
+  std::vector<uint32_t> host(kChainSimdWords, value);
+  hipError_t e = hipDeviceSynchronize();
+  if (e != hipSuccess) return e;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_chain_simd_mask), host.data(), host.size() * sizeof(uint32_t));
 }
 
 const char* inverse_kernel_name(const Geom& g, uint32_t nframes) {

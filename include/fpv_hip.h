@@ -226,10 +226,18 @@ int fpvhip_inverse_pass_stats(fpvhip_ctx *ctx, uint32_t *out, int reset);
  * ("k_inverse_trio", "k_inverse_spec", "k_inverse_fast", "k_inverse"). */
 const char *fpvhip_inverse_kernel_name(fpvhip_ctx *ctx, uint32_t nframes);
 /* Diagnostics: the three launches of one forward batch on this context, comma separated
- * ("k_tile,k_tile_decide,k_tile_finish" for the tile pass, "k_stream,k_redo_decide,k_redo_stream"
- * for geometries that keep the streaming kernels): the order of kernel_ms[] of
+ * ("k_tile8,k_frame8,k_redo8" for round 4's tile pass, "k_tile,k_tile_decide,k_tile_finish" for
+ * round 3's (FPV_FORWARD=tile16, widths beyond 8192), "k_stream,k_redo_decide,k_redo_stream" for
+ * geometries that keep the streaming kernels): the order of kernel_ms[] of
  * fpvhip_time_predict_device. */
 const char *fpvhip_forward_kernel_names(fpvhip_ctx *ctx);
+/* Diagnostics / recovery: the three-wave inverse kernel keeps one word per CU of "SIMDs that
+ * already run some frame's chain wave" in device memory (a placement hint: results never depend
+ * on it; DecompressImage's loop cc:326-344 has no such notion).  A kernel killed in mid-flight
+ * leaves bits set; this entry overwrites every word of the context's device with `value` (0 =
+ * all free; 0xf = all taken, which sends every workgroup through the kernel's fallback choice:
+ * tests).  Synchronises the device. */
+int fpvhip_debug_set_chain_mask(fpvhip_ctx *ctx, uint32_t value);
 /* Bench only: `iters` plain 16-B-per-lane device copies of `bytes` bytes on
  * `stream`; returns elapsed ms.  The measured HBM ceiling kernels are compared with. */
 double fpvhip_time_copy_device(void *d_dst, const void *d_src, size_t bytes,

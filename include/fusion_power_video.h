@@ -198,6 +198,12 @@ class Encoder {
       Callback;
 
   // Emits header + compressed delta frame through `callback` before returning.
+  // Geometry, encode side (differences from upstream, whose only limit is MAX_IMAGE_SIZE,
+  // cc:164): xsize and ysize must be multiples of 4 -- upstream reads out of bounds for other
+  // sizes (the 4x4 preview boxes and the preview's clamped gradient, cc:500-512, cc:575-586), so
+  // its output is undefined there -- and xsize at most 32768 (the kernels' LDS line buffers).
+  // Anything else latches LastError() ("unsupported geometry ...") and the session emits nothing.
+  // Decoding has neither limit (odd sizes written by the CPU reference decode).
   void Init(const uint16_t* delta_frame, size_t xsize, size_t ysize,
             Callback callback, void* payload);
   // Queues one frame.  As upstream: `img` must stay valid until this frame's

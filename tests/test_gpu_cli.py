@@ -81,29 +81,48 @@ def _bench_ms(binary, raw, threads, reps=3, env=None):
                     reason="needs the upstream benchmark built over this library and the CPU reference build")
 def test_upstream_benchmark_cold_start_vs_cpu_reference(raw100):
     """benchmark.cc:153-180 times Encoder construction -> Finish of a FRESH process: 100 frames
-    1280x800, this library under the unchanged upstream benchmark against the CPU reference
-    on the same box, best of three each.  Round 1 lost this at 32 and 64 threads (pinned
-    allocations and stream creation inside the timer).  The device warm-up (runtime, context,
-    first launches, first transfers) is LAZY by default since round 3 -- a process that merely
-    links the library no longer touches a GPU -- so a fresh process pays for it inside the timer;
-    FPV_WARMUP=eager is the documented setting for this kind of measurement (warm-up at library
-    load, round 2's behaviour) and the one the bounds apply to.  Both are recorded."""
-    table = {}
+    1280x800, this library under the unchanged upstream benchmark against the CPU reference on the
+    same box, best of three each, in the DEFAULT environment (lazy device bring-up: nothing touches
+    the GPU before the first Encoder) and with FPV_WARMUP=eager (bring-up at library load).
+
+    What the default can reach is bounded from below by the HIP runtime itself: tools/exp/cold_probe
+    (build/bin/cold_probe) measures what ANY fresh process pays before its first byte comes back from
+    the GPU -- runtime init, first launch (code object), a stream, the first transfer each way --
+    about 100-120 ms on this pool, i.e. MORE than the CPU reference needs for the whole 100-frame
+    job at 32 threads (about 90 ms).  The assertions therefore are: (a) the default adds no more
+    than that floor (+35 %) to the eager run -- the library's own share of the cold start is gone --
+    (b) regression guards on the default's ratio to the reference, (c) round 2's bounds for eager."""
+    floor = None
+    probe = os.path.join(BIN, "cold_probe")
+    if _have(probe):
+        vals = []
+        for _ in range(3):
+            r = subprocess.run([probe], capture_output=True, text=True, timeout=60)
+            m = re.search(r"total ([0-9.]+) ms", r.stdout)
+            if r.returncode == 0 and m:
+                vals.append(float(m.group(1)))
+        floor = min(vals) if vals else None
+    table = {"runtime_floor_ms_cold_probe": floor}
     for t in (8, 32, 64):
         ours = _bench_ms(os.path.join(BIN, "ref_benchmark"), raw100, t, env={"FPV_WARMUP": "eager"})
-        lazy = _bench_ms(os.path.join(BIN, "ref_benchmark"), raw100, t, reps=2)
+        lazy = _bench_ms(os.path.join(BIN, "ref_benchmark"), raw100, t)
         ref = _bench_ms(os.path.join(REF, "benchmark"), raw100, t)
-        table[t] = {"gpu_library_ms": ours, "gpu_library_lazy_warmup_ms": lazy, "cpu_reference_ms": ref,
-                    "fps_ratio": round(ref / ours, 3), "fps_ratio_lazy_warmup": round(ref / lazy, 3)}
+        table[t] = {"gpu_library_default_ms": lazy, "gpu_library_eager_warmup_ms": ours, "cpu_reference_ms": ref,
+                    "fps_ratio_default": round(ref / lazy, 3), "fps_ratio_eager_warmup": round(ref / ours, 3),
+                    "default_minus_eager_ms": round(lazy - ours, 1)}
     print(json.dumps(table))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(table, open(os.path.join(ROOT, "gpurun_out", "upstream_benchmark_vs_reference.json"), "w"), indent=1)
-    # Timing on a shared box swings (both sides burst beyond the CPU quota for a job this
-    # short): the bounds catch a regression to round 1 (0.5-0.6 at 32 and 64 threads), the
-    # table itself goes to gpurun_out/ and DESIGN.md.
-    assert table[8]["fps_ratio"] >= 0.9, table
-    assert table[32]["fps_ratio"] >= 0.9, table
-    assert table[64]["fps_ratio"] >= 0.7, table
+    # Timing on a shared box swings (both sides burst beyond the CPU quota for a job this short).
+    for t in (8, 32, 64):
+        if floor:
+            assert table[t]["default_minus_eager_ms"] <= 1.35 * floor + 15.0, table
+    assert table[8]["fps_ratio_default"] >= 0.55, table     # round 3: 0.52 / 0.31 / 0.25
+    assert table[32]["fps_ratio_default"] >= 0.38, table
+    assert table[64]["fps_ratio_default"] >= 0.33, table
+    assert table[8]["fps_ratio_eager_warmup"] >= 0.9, table
+    assert table[32]["fps_ratio_eager_warmup"] >= 0.9, table
+    assert table[64]["fps_ratio_eager_warmup"] >= 0.7, table
 
 
 @pytest.mark.skipif(not _have(os.path.join(BIN, "frame_rate")), reason="build/bin/frame_rate not built")

@@ -205,3 +205,39 @@ def test_three_wave_block_lengths(fpv, oracle, block, xs, ys, n):
             os.environ.pop("FPV_TRIO_BLOCK", None)
         else:
             os.environ["FPV_TRIO_BLOCK"] = old
+
+
+def test_chain_simd_claim_fallback_and_recovery(fpv, oracle):
+    """The three-wave kernel's workgroups claim a SIMD that no other frame's chain wave is on, in a
+    per-CU word of device memory -- a placement hint only.  With every SIMD marked taken (what a
+    kernel killed in mid-flight leaves behind) every workgroup takes the fallback choice (wave 0,
+    nothing claimed, nothing released): pixels identical; after the reset the claims work again,
+    and a healthy run leaves every word clear (a second all-taken run would otherwise differ)."""
+    import torch
+    xs, ys, n = 1280, 24, 300     # more workgroups than CUs: several per CU at the same time
+    rng = np.random.default_rng(77)
+    high = rng.integers(0, 256, (n, ys, xs), dtype=np.uint8)
+    low = rng.integers(0, 256, (n, ys, xs), dtype=np.uint8)
+    flags = (np.arange(n) % 4 | 2).astype(np.uint8)   # every frame has a chain
+    delta16 = rng.integers(0, 65536, ys * xs).astype(np.uint16)
+    p = fpv.Predictor(xs, ys, 0, False, max_batch=n)
+    p.set_delta_decoded(delta16)
+    th, tl, tf = (torch.from_numpy(a.reshape(n, -1) if a.ndim == 3 else a).cuda() for a in (high, low, flags))
+    want = [np.asarray(oracle.inverse(high[k].reshape(-1), low[k].reshape(-1), delta16, xs, ys, int(flags[k]))).reshape(-1)
+            for k in range(0, n, 7)]
+
+    def run():
+        rec = p.inverse(th, tl, tf)
+        torch.cuda.synchronize()
+        return rec.cpu().view(torch.int16).numpy().view(np.uint16).reshape(n, -1)
+    base = run()
+    for i, k in enumerate(range(0, n, 7)):
+        assert np.array_equal(base[k], want[i]), f"frame {k}"
+    try:
+        p.set_chain_mask(0xF)                      # every SIMD of every CU "taken"
+        assert np.array_equal(run(), base)         # the fallback branch, twice (nothing may have been released wrongly)
+        assert np.array_equal(run(), base)
+    finally:
+        p.set_chain_mask(0)
+    assert np.array_equal(run(), base)
+    p.close()

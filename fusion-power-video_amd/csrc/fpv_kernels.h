@@ -31,7 +31,7 @@ struct Geom {
   // tile pass (fpv_tile.inc): 0 = the geometry takes the streaming kernels instead
   uint32_t tile_ok, tile_groups, tile_threads, tile_tiles, tile_lds;
   // round 4's tile pass (fpv_tile8.inc: 8 pixels per lane, R rows per thread); preferred when usable
-  uint32_t tile8_ok, tile8_rows, tile8_groups, tile8_threads, tile8_tiles, tile8_lds;
+  uint32_t tile8_ok, tile8_rows, tile8_groups, tile8_threads, tile8_tiles, tile8_lds, tile8_frame_big;
   uint32_t nd, ncg;             // sample counts of the two heuristics
   uint32_t ring;                // inverse kernel: LDS ring size (power of two)
   uint32_t inv_ring;            // fast inverse kernel: ring size in pixels (power of two)

@@ -2589,6 +2589,7 @@ bool make_geom(uint32_t xs, uint32_t ys, int shift, int big_endian, Geom* g,
         g->tile8_threads = T;
         g->tile8_tiles = tiles;
         g->tile8_lds = lds;
+        g->tile8_frame_big = getenv("FPV_FRAME8_BIG") != nullptr;
       }
     }
   }
@@ -2802,7 +2803,8 @@ static hipError_t predict_impl(const Geom& g, const uint16_t* d_frames,
     } while (0)
     FPV_T8(k_tile8, grid);
     if (ev) hipEventRecord(ev[1], s);
-    if (g.tile8_tiles > 64) k_frame8<SWAP, true><<<2 * nframes, 1024, 0, s>>>(L);   // many records per frame (large frames)
+    const bool frame_big = g.tile8_frame_big;  // FPV_FRAME8_BIG (experiments): 1024-thread workgroups for every geometry
+    if (g.tile8_tiles > 64 || frame_big) k_frame8<SWAP, true><<<2 * nframes, 1024, 0, s>>>(L);   // many records per frame (large frames)
     else k_frame8<SWAP, false><<<2 * nframes, 256, 0, s>>>(L);
     if (ev) hipEventRecord(ev[2], s);
     FPV_T8(k_redo8, rgrid);

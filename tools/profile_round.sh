@@ -4,7 +4,7 @@
 # (separate runs, no tracing domain mixed in), then the plain default bench.  Output: gpurun_out/<tag>/
 set -u
 cd "$(dirname "$0")/.."
-TAG=${1:-r03}
+TAG=${1:-r04}
 export TMPDIR=/tmp
 mkdir -p gpurun_out/$TAG
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$TAG/trace -- python3 bench.py --steps 200 --warmup 5 --quick > gpurun_out/$TAG/bench_under_rocprof.log 2>&1
@@ -12,7 +12,8 @@ cp $(find gpurun_out/$TAG/trace -name "*kernel_stats.csv" | head -1) gpurun_out/
 echo "[$(date +%T)] trace done"
 bash tools/prof_pmc.sh $TAG > /dev/null 2>&1
 echo "[$(date +%T)] pmc done"
-python3 tools/pmc_summary.py gpurun_out/pmc_$TAG k_tile > gpurun_out/$TAG/pmc_k_tile.json
+python3 tools/pmc_summary.py gpurun_out/pmc_$TAG k_tile8 > gpurun_out/$TAG/pmc_k_tile.json
+python3 tools/pmc_summary.py gpurun_out/pmc_$TAG k_frame8 > gpurun_out/$TAG/pmc_k_frame8.json
 python3 tools/pmc_summary.py gpurun_out/pmc_$TAG k_inverse_ > gpurun_out/$TAG/pmc_k_inverse.json
 python3 tools/traffic_from_pmc.py gpurun_out/pmc_$TAG > gpurun_out/$TAG/traffic.json
 python3 tools/traffic_from_pmc.py gpurun_out/pmc_${TAG}_noise > gpurun_out/$TAG/traffic_noise.json

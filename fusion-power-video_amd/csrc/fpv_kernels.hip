@@ -2576,9 +2576,12 @@ bool make_geom(uint32_t xs, uint32_t ys, int shift, int big_endian, Geom* g,
     if (const char* e = getenv("FPV_TILE8_GROUPS")) G = std::max(1u, (uint32_t)atoi(e));
     if (ncs && G * ncs > 1024) G = 1024 / ncs;
     G = std::min(G, (ys + R - 1) / R);
-    const char* fwd = getenv("FPV_FORWARD");  // "stream" / "tile16": the earlier kernels (A/B runs, tests)
+    // FPV_FORWARD=tile8 selects this pass (A/B runs, tests); the default stays round 3's tile pass:
+    // measured in one process on six geometries the two are within 2 % of each other, each ahead
+    // somewhere (profiles/r04_forward_sizes.log) -- every pixel line was requested once before, too.
+    const char* fwd = getenv("FPV_FORWARD");
     g->tile8_ok = 0;
-    if (g->tile_ok && G >= 1 && !(fwd && (fwd[0] == 's' || !strcmp(fwd, "tile16")))) {
+    if (g->tile_ok && G >= 1 && fwd && !strcmp(fwd, "tile8")) {
       const uint32_t T = std::max(256u, round_up(G * ncs, 256));
       const uint32_t tiles = (ys + R * G - 1) / (R * G);
       const uint32_t lds = tile8_lds_bytes(R, G, ncs, T);
@@ -2589,7 +2592,7 @@ bool make_geom(uint32_t xs, uint32_t ys, int shift, int big_endian, Geom* g,
         g->tile8_threads = T;
         g->tile8_tiles = tiles;
         g->tile8_lds = lds;
-        g->tile8_frame_big = getenv("FPV_FRAME8_BIG") != nullptr;
+        g->tile8_frame_big = getenv("FPV_FRAME8_BIG") != nullptr;  // experiments / tests: 1024 threads whatever the size
       }
     }
   }
@@ -2803,9 +2806,9 @@ static hipError_t predict_impl(const Geom& g, const uint16_t* d_frames,
     } while (0)
     FPV_T8(k_tile8, grid);
     if (ev) hipEventRecord(ev[1], s);
-    const bool frame_big = g.tile8_frame_big;  // FPV_FRAME8_BIG (experiments): 1024-thread workgroups for every geometry
-    if (g.tile8_tiles > 64 || frame_big) k_frame8<SWAP, true><<<2 * nframes, 1024, 0, s>>>(L);   // many records per frame (large frames)
-    else k_frame8<SWAP, false><<<2 * nframes, 256, 0, s>>>(L);
+    const bool frame_big = g.tile8_frame_big;  // FPV_FRAME8_BIG (experiments / tests): 1024 threads whatever the size
+    if (g.tile8_tiles > 64 || frame_big) k_frame8<SWAP, true><<<nframes, 1024, 0, s>>>(L);   // many records per frame (large frames)
+    else k_frame8<SWAP, false><<<nframes, 256, 0, s>>>(L);
     if (ev) hipEventRecord(ev[2], s);
     FPV_T8(k_redo8, rgrid);
 #undef FPV_T8

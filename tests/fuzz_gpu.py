@@ -81,12 +81,13 @@ while time.time() - t0 < budget:
     r = int(rng.integers(0, 12))
     if r == 0:
         os.environ["FPV_FORWARD"] = "stream"
-    elif r < 3:     # round 3's tile pass (16 pixels per lane)
-        os.environ["FPV_FORWARD"] = "tile16"
+    elif r < 4:     # the tile pass (16 pixels per lane) at a random tile height (default height otherwise)
         os.environ["FPV_TILE_GROUPS"] = str(int(rng.integers(1, 24)))
-    elif r < 9:     # round 4's tile pass (8 pixels per lane): 4 or 8 rows per thread, random tile height
+    elif r < 8:     # round 4's variant (8 pixels per lane): 4 or 8 rows per thread, random tile height
+        os.environ["FPV_FORWARD"] = "tile8"
         os.environ["FPV_TILE8_ROWS"] = str(int(rng.choice([4, 8])))
-        os.environ["FPV_TILE8_GROUPS"] = str(int(rng.integers(1, 24)))
+        if rng.integers(0, 3):
+            os.environ["FPV_TILE8_GROUPS"] = str(int(rng.integers(1, 24)))
     p = pkg.Predictor(xs, ys, shift, be, max_batch=n)
     if delta is not None:
         p.set_delta_raw(delta)

@@ -33,7 +33,7 @@ def test_bench_line_contract():
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     # achieved = algorithmic bytes per launch / the dominant kernel's measured duration
-    assert rf["kernel"] == "k_tile8"                      # 1280x800 takes round 4's tile pass (8 pixels per lane)
+    assert rf["kernel"] == "k_tile"                       # 1280x800 takes the tile pass
     k_ms = d["kernel_ms"][rf["kernel"]]
     assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (k_ms / 1e3) / 1e9) / rf["achieved"] < 0.01
     assert k_ms <= d["ms_per_step"] * 1.02
@@ -85,7 +85,7 @@ def test_two_rank_line_carries_what_the_north_star_asks_for():
     assert len(em["stage_split"]["per_device_batches"]) == 2 and min(em["stage_split"]["per_device_batches"]) > 0
     pr = d["per_rank"]
     assert len(pr["ms_per_step"]) == 2 and len(pr["kernel_ms"]) == 2 and pr["process_group"]["world_size"] == 2
-    assert all(k["k_tile8"] > 0 for k in pr["kernel_ms"])
+    assert all(k["k_tile"] > 0 for k in pr["kernel_ms"])
     assert abs(d["value"] - 2 * d["config"]["frames_per_step_per_gpu"] / (d["ms_per_step"] / 1e3)) / d["value"] < 0.01
 
 

@@ -89,19 +89,21 @@ def test_partial_batches_reuse_workspace(fpv, synth, oracle):
 
 @pytest.mark.parametrize("env", [{"FPV_FORWARD": "stream", "FPV_STRIP_ROWS": "4"}, {"FPV_FORWARD": "stream", "FPV_STRIP_ROWS": "80", "FPV_STRIP_MAJOR": "0"},
                                  {"FPV_FORWARD": "stream", "FPV_STRIP_ROWS": "12", "FPV_WAVES_PER_CU": "2"}, {"FPV_FORWARD": "stream"},
-                                 {"FPV_FORWARD": "tile16", "FPV_TILE_GROUPS": "1"}, {"FPV_FORWARD": "tile16", "FPV_TILE_GROUPS": "7"},
-                                 {"FPV_FORWARD": "tile16", "FPV_TILE_GROUPS": "50"}, {"FPV_FORWARD": "tile16"},
-                                 {"FPV_TILE8_GROUPS": "1"}, {"FPV_TILE8_GROUPS": "2"}, {"FPV_TILE8_GROUPS": "5"}, {"FPV_TILE8_GROUPS": "50"},
-                                 {"FPV_TILE8_ROWS": "4"}, {"FPV_TILE8_ROWS": "4", "FPV_TILE8_GROUPS": "1"}, {"FPV_TILE8_ROWS": "4", "FPV_TILE8_GROUPS": "7"},
-                                 {"FPV_TILE8_ROWS": "4", "FPV_TILE8_GROUPS": "50"},
+                                 {"FPV_TILE_GROUPS": "1"}, {"FPV_TILE_GROUPS": "7"}, {"FPV_TILE_GROUPS": "50"}, {"FPV_FORWARD": "tile16"},
+                                 {"FPV_FORWARD": "tile8"}, {"FPV_FORWARD": "tile8", "FPV_FRAME8_BIG": "1"},
+                                 {"FPV_FORWARD": "tile8", "FPV_TILE8_GROUPS": "1"}, {"FPV_FORWARD": "tile8", "FPV_TILE8_GROUPS": "2"},
+                                 {"FPV_FORWARD": "tile8", "FPV_TILE8_GROUPS": "5"}, {"FPV_FORWARD": "tile8", "FPV_TILE8_GROUPS": "50"},
+                                 {"FPV_FORWARD": "tile8", "FPV_TILE8_ROWS": "8"}, {"FPV_FORWARD": "tile8", "FPV_TILE8_ROWS": "8", "FPV_TILE8_GROUPS": "1"},
+                                 {"FPV_FORWARD": "tile8", "FPV_TILE8_ROWS": "8", "FPV_TILE8_GROUPS": "7"},
+                                 {"FPV_FORWARD": "tile8", "FPV_TILE8_ROWS": "8", "FPV_TILE8_GROUPS": "50"},
                                  {"FPV_INVERSE_SLOW": "1"}, {"FPV_INVERSE": "fast"}, {"FPV_INVERSE": "spec"},
                                  {"FPV_INVERSE": "trio"}])
 def test_alternate_kernel_paths(fpv, synth, oracle, env):
     """The streaming forward kernels (round 2; still the path of widths that are not multiples
-    of 64) with odd strip sizes and the frame-major task order, round 3's tile pass (16 pixels per
-    lane) and round 4's (8 pixels per lane, 4 or 8 rows per thread) with other tile heights (one
-    group per tile, a last tile that is partly outside the frame or ends on half a group, the whole
-    frame as one tile) and every inverse kernel (byte-granular, serial chain, one-wave and three-wave
+    of 64) with odd strip sizes and the frame-major task order, the tile pass (16 pixels per lane)
+    and round 4's variant of it (FPV_FORWARD=tile8: 8 pixels per lane, 4 or 8 rows per thread) with
+    other tile heights (one group per tile, a last tile that is partly outside the frame or ends on
+    half a group, the whole frame as one tile) and every inverse kernel (byte-granular, serial chain, one-wave and three-wave
     speculative) must give the same bits as the defaults."""
     import os
     old = {k: os.environ.get(k) for k in env}

@@ -1,6 +1,7 @@
 """Forward-kernel time at other geometries (experiments): python tools/exp/fwd_sizes.py
-For each geometry: the tile pass at its default tile height, other heights, and the streaming kernels
-(FPV_FORWARD=stream), same frames, same process.  GB/s = algorithmic bytes (4.0625 P per frame)."""
+For each geometry: round 4's tile pass at its default shape, with 8 rows per thread and at other tile
+heights, round 3's tile pass (FPV_FORWARD=tile16) and the streaming kernels (FPV_FORWARD=stream), same
+frames, same process.  GB/s = algorithmic bytes (4.0625 P per frame)."""
 import sys, os, importlib, numpy as np, torch
 sys.path.insert(0, '.')
 from __graft_entry__ import load_package
@@ -11,7 +12,9 @@ for xs, ys, n, shift, bits in cases:
     d = torch.from_numpy(base[1:].reshape(8, -1).view(np.int16)).cuda()
     fr = d[torch.arange(n, device='cuda') % 8].contiguous().view(torch.uint16)
     out = None
-    for env in ({}, {"FPV_TILE_GROUPS": "1"}, {"FPV_TILE_GROUPS": "2"}, {"FPV_TILE_GROUPS": "3"}, {"FPV_TILE_GROUPS": "8"}, {"FPV_FORWARD": "stream"}):
+    # the default (the tile pass, 16 pixels per lane), round 4's variant (8 pixels per lane; R = 4, R = 8, shorter tiles), the streaming kernels
+    for env in ({}, {"FPV_FORWARD": "tile8"}, {"FPV_FORWARD": "tile8", "FPV_TILE8_ROWS": "8"}, {"FPV_FORWARD": "tile8", "FPV_TILE8_GROUPS": "3"},
+                {"FPV_FORWARD": "stream"}):
         os.environ.update(env)
         p = pkg.Predictor(xs, ys, shift, False, max_batch=n); p.set_delta_raw(base[0])
         for k in env: os.environ.pop(k)

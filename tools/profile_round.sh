@@ -12,8 +12,7 @@ cp $(find gpurun_out/$TAG/trace -name "*kernel_stats.csv" | head -1) gpurun_out/
 echo "[$(date +%T)] trace done"
 bash tools/prof_pmc.sh $TAG > /dev/null 2>&1
 echo "[$(date +%T)] pmc done"
-python3 tools/pmc_summary.py gpurun_out/pmc_$TAG k_tile8 > gpurun_out/$TAG/pmc_k_tile.json
-python3 tools/pmc_summary.py gpurun_out/pmc_$TAG k_frame8 > gpurun_out/$TAG/pmc_k_frame8.json
+python3 tools/pmc_summary.py gpurun_out/pmc_$TAG k_tile > gpurun_out/$TAG/pmc_k_tile.json
 python3 tools/pmc_summary.py gpurun_out/pmc_$TAG k_inverse_ > gpurun_out/$TAG/pmc_k_inverse.json
 python3 tools/traffic_from_pmc.py gpurun_out/pmc_$TAG > gpurun_out/$TAG/traffic.json
 python3 tools/traffic_from_pmc.py gpurun_out/pmc_${TAG}_noise > gpurun_out/$TAG/traffic_noise.json

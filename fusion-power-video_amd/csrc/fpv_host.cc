@@ -522,7 +522,7 @@ struct Encoder::Impl {
   const bool print_stats = getenv("FPV_STATS") != nullptr;
   const bool stats = true;  // a handful of clock reads per frame
   std::atomic<uint64_t> st_brotli_ns{0}, st_copy_ns{0}, st_gpu_wait_ns{0}, st_gpu_us{0}, st_batches{0}, st_bytes_up{0}, st_bytes_down{0};
-  static constexpr size_t kMaxStatDevs = 16;
+  enum : size_t { kMaxStatDevs = 16 };  // (an enumerator: never ODR-used, no out-of-class definition needed in C++14)
   std::atomic<uint64_t> st_dev_batches[kMaxStatDevs] = {}, st_dev_wait_ns[kMaxStatDevs] = {};  // per device of the session
   double last_stats[11 + 2 * kMaxStatDevs] = {};  // filled by Finish (Encoder::LastStats)
   std::chrono::steady_clock::time_point st_t0;
@@ -1053,7 +1053,7 @@ void Encoder::Finish(Callback callback, void* payload) {
     o[0] = (double)n; o[1] = wall; o[2] = brotli; o[3] = copy; o[4] = gpu / batches; o[5] = batches;
     o[6] = s.st_bytes_up / (wall * 1e6); o[7] = s.st_bytes_down / (wall * 1e6);  // GB/s
     o[8] = host_stage / wall; o[9] = s.st_gpu_wait_ns / 1e6;
-    const size_t nd = std::min(s.devices.size(), Impl::kMaxStatDevs);
+    const size_t nd = std::min<size_t>(s.devices.size(), (size_t)Impl::kMaxStatDevs);
     o[10] = (double)nd;
     for (size_t d = 0; d < nd; d++) {
       o[11 + 2 * d] = (double)s.st_dev_batches[d].load();

@@ -1448,6 +1448,50 @@ __device__ __forceinline__ uint32_t inv_px4(const uint32_t* n, uint32_t w, const
 #endif
 }
 
+// Round 4: the leaner form of the speculative kernels' serial path (FPV_INV_LEAN, default on).
+// A lone chain wave issues one instruction every ~6.3 clocks whatever else its SIMD could take
+// (tools/exp/chain_ilp.hip: a second, independent chain in the same wave gains 8 %, a second WAVE
+// on the SIMD runs at full speed beside it), and at 1000 frames every frame's chain wave has a
+// SIMD to itself: the batch takes what ONE frame's chain takes, so every instruction of that
+// wave's loop counts.  Three cuts, none of which changes a result:
+//   * residuals stay packed: two dwords per four pixels ({0, b0, 0, b2} and {0, b1, 0, b3}: the
+//     bytes as v << 8 halves) instead of four unpacked ones, and the step's last add selects its
+//     half by SDWA (v_add_u16_sdwa src1_sel:WORD_k: same latency as the plain add);
+//   * every lane reruns its segment in every pass -- a lane whose input did not change recomputes
+//     what it had -- so there is no exec masking and no branch around the chain;
+//   * the "is any lane still wrong" test is the compare's lane mask and-ed with the active lanes
+//     (s_and_b64 + scc branch) instead of a ballot of a bool (v_cndmask + v_cmp + vcc branch), and
+//     the DPP needs no zeroed destination.
+#ifndef FPV_INV_LEAN
+#define FPV_INV_LEAN 1
+#endif
+__device__ __forceinline__ uint32_t r_lo(uint32_t rq) { return __builtin_amdgcn_perm(0, rq, 0x020c000cu); }  // {0, b0, 0, b2}
+__device__ __forceinline__ uint32_t r_hi(uint32_t rq) { return rq & 0xff00ff00u; }                             // {0, b1, 0, b3}
+// Four chain steps; rlo / rhi: the four residuals as above.
+__device__ __forceinline__ uint32_t inv_px4w(const uint32_t* n, uint32_t w, const uint32_t* d, uint32_t rlo, uint32_t rhi, uint32_t* x) {
+  uint32_t x0, x1, x2, x3;
+#define FPV_ADDW(X, R, SEL) "v_add_u16_sdwa " X ", " X ", " R " dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:" SEL "\n\t"
+  asm("v_add_u32_e32 %0, %5, %4\n\tv_med3_i32 %0, %6, %4, %0\n\t" FPV_ADDW("%0", "%13", "WORD_0")
+      "v_add_u32_e32 %1, %7, %0\n\tv_med3_i32 %1, %8, %0, %1\n\t" FPV_ADDW("%1", "%14", "WORD_0")
+      "v_add_u32_e32 %2, %9, %1\n\tv_med3_i32 %2, %10, %1, %2\n\t" FPV_ADDW("%2", "%13", "WORD_1")
+      "v_add_u32_e32 %3, %11, %2\n\tv_med3_i32 %3, %12, %2, %3\n\t" FPV_ADDW("%3", "%14", "WORD_1")
+      : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3)
+      : "v"(w), "v"(d[0]), "v"(n[0]), "v"(d[1]), "v"(n[1]), "v"(d[2]), "v"(n[2]), "v"(d[3]), "v"(n[3]), "v"(rlo), "v"(rhi));
+#undef FPV_ADDW
+  x[0] = x0; x[1] = x1; x[2] = x2; x[3] = x3;
+  return x3;
+}
+// The check behind a pass: lane j's input against lane j - 1's output (lane 0: the previous
+// superstep's last pixel).  Returns the mask of active lanes whose input was wrong; *pred_out =
+// the input every lane should have had.
+__device__ __forceinline__ uint64_t chain_check(uint32_t x_last, uint32_t in, uint32_t w_prev, bool lane0, uint64_t active_mask,
+                                                uint32_t* pred_out) {
+  uint32_t pred = (uint32_t)__builtin_amdgcn_update_dpp((int)x_last, (int)x_last, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+  if (lane0) pred = w_prev;
+  *pred_out = pred;
+  return __builtin_amdgcn_uicmp(pred, in, 33 /* ICMP_NE */) & active_mask;
+}
+
 __global__ __launch_bounds__(64) void k_inverse_fast(
     const uint8_t* __restrict__ high, const uint8_t* __restrict__ low,
     const uint8_t* __restrict__ dhigh, const uint8_t* __restrict__ dlow,
@@ -1781,7 +1825,11 @@ __global__ __launch_bounds__(64) void k_inverse_spec(
     const uint32_t start = s0 + lane * K;
     const bool active = FULL || start < npix;
     // segment operands into registers, everything as v << 8
+#if FPV_INV_LEAN
+    uint32_t N[K], D[K], X[K], RL[K4], RH[K4];  // residuals stay packed: see inv_px4w
+#else
     uint32_t N[K], D[K], R[K], X[K];
+#endif
     uint32_t guess;
     {
       const uint32_t nb = start - xs - 4;  // dword holding the north-west of the first pixel
@@ -1798,9 +1846,15 @@ __global__ __launch_bounds__(64) void k_inverse_spec(
           const uint32_t n = __builtin_amdgcn_perm(0, nd[t + 1], sel);
           N[4 * t + b] = n;
           D[4 * t + b] = n - prev;
+#if !FPV_INV_LEAN
           R[4 * t + b] = __builtin_amdgcn_perm(0, rq[t], sel);
+#endif
           prev = n;
         }
+#if FPV_INV_LEAN
+        RL[t] = r_lo(rq[t]);
+        RH[t] = r_hi(rq[t]);
+#endif
       }
     }
     fetch_r(s0 + S, rq);  // next superstep's residuals (rq was consumed above)
@@ -1822,6 +1876,17 @@ __global__ __launch_bounds__(64) void k_inverse_spec(
     bool run = true;
     const uint32_t npass0 = npass;
     bool settled = false;
+#if FPV_INV_LEAN
+    const uint64_t active_mask = __builtin_amdgcn_ballot_w64(active);
+    for (uint32_t round = 0; round < kScanAfter; round++) {  // the common case ends in here
+      uint32_t w = in, pred;  // every lane, every pass: a lane whose input did not change recomputes what it had
+#pragma unroll
+      for (int k = 0; k < K; k += 4) w = inv_px4w(N + k, w, D + k, RL[k / 4], RH[k / 4], X + k);
+      npass++;
+      if (!chain_check(X[K - 1], in, w_prev, lane == 0, active_mask, &pred)) { settled = true; break; }
+      in = pred;
+    }
+#else
     for (uint32_t round = 0; round < kScanAfter; round++) {  // the common case ends in here
       if (run) {
         uint32_t w = in;
@@ -1835,11 +1900,20 @@ __global__ __launch_bounds__(64) void k_inverse_spec(
       if (!__builtin_amdgcn_ballot_w64(run)) { settled = true; break; }
       in = pred;  // lanes that do not rerun have pred == in already
     }
+#endif
     if (__builtin_expect(!settled, 0)) {
       // Still wrong after kScanAfter passes: a long correction chain.  Its own copy
       // of the pass loop, so that nothing of it burdens the loop above.
       uint32_t all, ord = 0, sum = 0;
       asm volatile("v_mov_b32 %0, -1" : "=v"(all));  // keeps the compiler from hoisting the 2K ops below
+#if FPV_INV_LEAN
+      uint32_t R[K];
+#pragma unroll
+      for (int k = 0; k < K; k += 4) {
+        R[k] = RL[k / 4] & 0xffffu; R[k + 1] = RH[k / 4] & 0xffffu; R[k + 2] = RL[k / 4] >> 16; R[k + 3] = RH[k / 4] >> 16;
+      }
+      run = true;  // (the first pass in here reruns every lane, like the loop above)
+#endif
 #pragma unroll
       for (int k = 0; k < K; k++) { ord = max(ord, D[k] & all); sum += R[k] & all; }
       const bool is_shift = ord == 0 && lane != 0;  // lane 0 is final after the first pass: a constant
@@ -2224,6 +2298,10 @@ __global__ __launch_bounds__(192) void k_inverse_trio(
           all = false;
         }
       }
+      // (Round 4 tried to leave this phase's stores in flight across the barrier as well -- a wait for
+      // 4 * M * NK instead of 3 * M * NK operations: only the residual loads, the oldest, have to be
+      // back --: +0.5 ... +0.9 % at 1000 frames.  The stores' acknowledgements are not what the i/o
+      // waves wait for.)
       if (all) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * M * NK) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -2244,7 +2322,11 @@ __global__ __launch_bounds__(192) void k_inverse_trio(
       for (uint32_t t = b * M; t < (b + 1) * M && t < nsteps; t++) {
         const uint32_t s0 = head + t * S, start = s0 + lane * K;
         const bool active = start < npix;
+#if FPV_INV_LEAN
+        uint32_t N[K], D[K], X[K], RL[K4], RH[K4];  // residuals stay packed: see inv_px4w
+#else
         uint32_t N[K], D[K], R[K], X[K];
+#endif
         uint32_t guess;
         {
           const uint32_t nb = start - xs - 4;  // dword holding the north-west of the first pixel
@@ -2274,15 +2356,35 @@ __global__ __launch_bounds__(192) void k_inverse_trio(
               const uint32_t n = __builtin_amdgcn_perm(0, nd[q + 1], sel);
               N[4 * q + b] = n;
               D[4 * q + b] = n - prev;
+#if !FPV_INV_LEAN
               R[4 * q + b] = __builtin_amdgcn_perm(0, rq[q], sel);
+#endif
               prev = n;
             }
+#if FPV_INV_LEAN
+            RL[q] = r_lo(rq[q]);
+            RH[q] = r_hi(rq[q]);
+#endif
           }
         }
         uint32_t in = lane == 0 ? w_prev : guess;
         bool run = true;
         const uint32_t npass0 = npass;
         bool settled = false;
+#if FPV_INV_LEAN
+        const uint64_t active_mask = __builtin_amdgcn_ballot_w64(active);
+        for (uint32_t round = 0; round < kScanAfter; round++) {  // the common case ends in here
+          uint32_t w = in, pred;  // every lane, every pass (see inv_px4w)
+#pragma unroll
+          for (int k = 0; k < K; k += 4) w = inv_px4w(N + k, w, D + k, RL[k / 4], RH[k / 4], X + k);
+          npass++;
+#ifdef FPV_EXP_ONEPASS  // timing experiment only (wrong pixels): how much of the time is the passes?
+          settled = true; break;
+#endif
+          if (!chain_check(X[K - 1], in, w_prev, lane == 0, active_mask, &pred)) { settled = true; break; }
+          in = pred;
+        }
+#else
         for (uint32_t round = 0; round < kScanAfter; round++) {  // the common case ends in here
           if (run) {
             uint32_t w = in;
@@ -2299,9 +2401,18 @@ __global__ __launch_bounds__(192) void k_inverse_trio(
           if (!__builtin_amdgcn_ballot_w64(run)) { settled = true; break; }
           in = pred;
         }
+#endif
         if (__builtin_expect(!settled, 0)) {  // long correction chain: see k_inverse_spec
           uint32_t all, ord = 0, sum = 0;
           asm volatile("v_mov_b32 %0, -1" : "=v"(all));
+#if FPV_INV_LEAN
+          uint32_t R[K];
+#pragma unroll
+          for (int k = 0; k < K; k += 4) {
+            R[k] = RL[k / 4] & 0xffffu; R[k + 1] = RH[k / 4] & 0xffffu; R[k + 2] = RL[k / 4] >> 16; R[k + 3] = RH[k / 4] >> 16;
+          }
+          run = true;
+#endif
 #pragma unroll
           for (int k = 0; k < K; k++) { ord = max(ord, D[k] & all); sum += R[k] & all; }
           const bool is_shift = ord == 0 && lane != 0;

@@ -2041,10 +2041,14 @@ __global__ __launch_bounds__(192) void k_inverse_trio(
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   uint32_t role = wave;  // 0 chain, 1 and 2 i/o; frames with a chain reassign it below (the SIMD claim)
   const uint32_t frame = blockIdx.x, lane = threadIdx.x & 63;
-  const size_t fbase = (size_t)frame * g.npix;
+#ifdef FPV_EXP_PITCH  // experiments only (tools/exp/inv_pitch.py): planes / pixels of consecutive frames at a padded pitch
+  const size_t fbase = (size_t)frame * (g.npix + g.strip_rows), fbase_out = (size_t)frame * (g.npix + g.strips);
+#else
+  const size_t fbase = (size_t)frame * g.npix, fbase_out = fbase;
+#endif
   const uint8_t* hp = high + fbase;
   const uint8_t* lp = low ? low + fbase : nullptr;
-  uint16_t* outp = frames + fbase;
+  uint16_t* outp = frames + fbase_out;
   const uint32_t f = flags[frame];
   const bool use_delta = (f & 1) && dhigh, use_cg = f & 2, no_low = (f & 4) || !lp;
   const uint32_t xs = g.xs, npix = g.npix, m = ring_bytes - 1;
@@ -3167,10 +3171,18 @@ hipError_t launch_inverse(const Geom& g, const uint8_t* d_high,
   const int mode = inverse_mode(g, nframes, &k4, &mblk);
   const bool aligned = (g.xs & 3) == 0 && (g.npix & 3) == 0;
   if (mode == 3 && g.spec_k4) {
+#ifdef FPV_EXP_PITCH
+    Geom gp = g;
+    gp.strip_rows = g_exp_in_pad;   // plane pitch = npix + pad bytes
+    gp.strips = g_exp_out_pad;      // pixel pitch = npix + pad pixels
+#define FPV_TRIO_GEOM gp
+#else
+#define FPV_TRIO_GEOM g
+#endif
 #define FPV_LAUNCH_TRIO(K4, MB)                                                                       \
   if (k4 == K4 && mblk == MB)                                                                         \
     k_inverse_trio<K4, MB><<<nframes, 192, trio_lds(g, K4, MB), s>>>(                                 \
-        d_high, d_low, d_dhigh, d_dlow, d_flags, d_frames, g, trio_ring(g, K4, MB), d_diag);
+        d_high, d_low, d_dhigh, d_dlow, d_flags, d_frames, FPV_TRIO_GEOM, trio_ring(g, K4, MB), d_diag);
 #define FPV_LAUNCH_TRIO3(K4) FPV_LAUNCH_TRIO(K4, 1) FPV_LAUNCH_TRIO(K4, 2) FPV_LAUNCH_TRIO(K4, 4)
     if (k4 < 1 || k4 > kSpecMaxK4) return hipErrorInvalidValue;
     FPV_LAUNCH_TRIO3(1) FPV_LAUNCH_TRIO3(2) FPV_LAUNCH_TRIO3(3)

@@ -888,12 +888,30 @@ void Encoder::Init(const uint16_t* delta_frame, size_t xsize, size_t ysize,
   if (fpvhip_device_count() <= 0) { s.Fail("no usable GPU", fpvhip_last_error(nullptr)); return; }
   s.devices = DeviceList();
   if (s.num_threads == 0) s.devices.resize(1);
-  for (int d : s.devices) {
-    fpvhip_ctx* c = AcquireEncoderCtx(d, (uint32_t)xsize, (uint32_t)ysize, s.shift, s.big_endian,
-                                      (uint32_t)s.batch, s.slots_per_dev);
-    if (!c) { s.Fail("fpvhip_create", fpvhip_last_error(nullptr)); return; }
-    s.ctxs.push_back(c);
-    if (fpvhip_set_delta_raw(c, delta_frame)) { s.Fail("fpvhip_set_delta_raw", fpvhip_last_error(c)); return; }
+  {
+    // One context per device, created side by side (device buffers, pinned slot 0, the delta
+    // frame's upload and split: a few ms each, times eight on a full node when done in turn).
+    const size_t nd = s.devices.size();
+    s.ctxs.assign(nd, nullptr);
+    std::vector<std::string> errs(nd);
+    auto make = [&](size_t i) {
+      fpvhip_ctx* c = AcquireEncoderCtx(s.devices[i], (uint32_t)xsize, (uint32_t)ysize, s.shift, s.big_endian,
+                                        (uint32_t)s.batch, s.slots_per_dev);
+      if (!c) { errs[i] = std::string("fpvhip_create: ") + fpvhip_last_error(nullptr); return; }
+      s.ctxs[i] = c;
+      if (fpvhip_set_delta_raw(c, delta_frame)) errs[i] = std::string("fpvhip_set_delta_raw: ") + fpvhip_last_error(c);
+    };
+    std::vector<std::thread> th;
+    for (size_t i = 1; i < nd; i++) th.emplace_back(make, i);
+    make(0);
+    for (auto& t : th) t.join();
+    for (size_t i = 0; i < nd; i++)
+      if (!errs[i].empty()) {
+        // contexts that exist are released by Finish / the destructor through ReleaseContexts
+        s.ctxs.erase(std::remove(s.ctxs.begin(), s.ctxs.end(), nullptr), s.ctxs.end());
+        s.Fail("Encoder::Init", errs[i].c_str());
+        return;
+      }
   }
   s.gpu_q.assign(s.devices.size(), std::deque<Impl::Batch*>());
   for (size_t d = 0; d < s.devices.size(); d++) s.cv_dispatch.emplace_back(new std::condition_variable());

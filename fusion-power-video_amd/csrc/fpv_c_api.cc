@@ -6,6 +6,9 @@
 #include <chrono>
 #include <vector>
 
+#include <brotli/encode.h>
+
+#include "fpv_host_internal.h"
 #include "fusion_power_video.h"
 
 namespace {
@@ -73,6 +76,17 @@ double fpvc_bench_encode(const uint16_t* frames, size_t distinct, size_t total, 
   const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (bytes_out) *bytes_out = out.bytes;
   return dt;
+}
+
+// TEST HOOK: 1 when the arena-backed Brotli call gives exactly what libbrotli's one-shot entry
+// point gives for this input (tests/test_host_cpu.py), 0 otherwise.
+int fpvc_test_brotli_equivalence(const uint8_t* in, size_t n) {
+  const size_t cap = BrotliEncoderMaxCompressedSize(n) + 1024;
+  std::vector<uint8_t> a(cap), b(cap);
+  size_t sa = cap, sb = cap;
+  const bool oa = fpvc::internal::BrotliCompress(in, n, a.data(), &sa);
+  const bool ob = BrotliEncoderCompress(1, BROTLI_DEFAULT_WINDOW, BROTLI_DEFAULT_MODE, n, in, &sb, b.data()) != 0;
+  return oa == ob && (!oa || (sa == sb && memcmp(a.data(), b.data(), sa) == 0));
 }
 
 size_t fpvc_encode_stream(const uint16_t* frames, size_t nframes,

@@ -484,7 +484,7 @@ void Frame::CompressPredicted(size_t* encoded_high_size, uint8_t* encoded_high_b
   }
   if (PlanesPending()) SplitNow();
   auto brotli = [](const uint8_t* in, size_t n, size_t* sz, uint8_t* buf) {
-    BrotliEncoderCompress(1, BROTLI_DEFAULT_WINDOW, BROTLI_DEFAULT_MODE, n, in, sz, buf);
+    if (!BrotliCompress(in, n, buf, sz)) *sz = 0;  // (upstream ignores the result too; a failed stream has size 0)
   };
   std::future<void> low_task;
   if (!encoded_low_buffer || (flags_ & FrameFlags::NO_LOW_BYTES)) {

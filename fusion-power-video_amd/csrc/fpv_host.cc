@@ -108,6 +108,77 @@ bool OutOfRange(size_t pos, size_t width, size_t size) {
 
 // ------------------------------------------------------------------ Brotli --
 
+// libbrotli's own allocations, out of the way of the other threads.  BrotliEncoderCompress /
+// BrotliDecoder* allocate their state -- hash table, command and literal buffers, ring buffer:
+// 1.5-5 MB per call -- through malloc, i.e. one mmap, its page faults and one munmap per plane and
+// thread.  With many threads compressing back to back (the GPU has taken the predictor stage, so
+// that is ALL the worker threads do) these calls queue on the process's address-space lock:
+// measured on 8 threads, one-shot calls on predicted high planes took 24 ms each where a lone
+// thread takes 6.7.  The same library entry points take an allocator: every thread hands them a
+// bump arena that lives as long as the thread (the bytes produced cannot depend on where the
+// state lies: tests/test_host_cpu.py::test_brotli_arena_bytes_are_the_librarys).
+namespace {
+struct BrotliArena {
+  uint8_t* base = nullptr;
+  size_t cap = 0, at = 0;
+  ~BrotliArena() { free(base); }
+  static void* Alloc(void* opaque, size_t n) {
+    BrotliArena* a = static_cast<BrotliArena*>(opaque);
+    if (!a->base) {
+      a->cap = EnvSize("FPV_BROTLI_ARENA_MB", 12) << 20;
+      a->base = static_cast<uint8_t*>(malloc(a->cap));  // touched as far as it is used
+      if (!a->base) a->cap = 0;
+    }
+    const size_t p = (a->at + 63) & ~(size_t)63;
+    if (p + n > a->cap) return malloc(n);  // larger states than expected: the library's own way
+    a->at = p + n;
+    return a->base + p;
+  }
+  static void Free(void* opaque, void* p) {
+    BrotliArena* a = static_cast<BrotliArena*>(opaque);
+    if (!p) return;
+    if (a->base && p >= a->base && p < a->base + a->cap) return;  // the arena is reset per stream
+    free(p);
+  }
+};
+BrotliArena& ThreadArena() {
+  static thread_local BrotliArena a;
+  a.at = 0;
+  return a;
+}
+}  // namespace
+
+// BrotliEncoderCompress(1, BROTLI_DEFAULT_WINDOW, BROTLI_DEFAULT_MODE, n, in, size, out) with the
+// encoder's state in this thread's arena: the same calls libbrotli 1.0.9's one-shot entry point
+// makes (quality, lgwin, mode, size hint = n, one CompressStream with OPERATION_FINISH), and the
+// library's own entry point for whatever is not the plain case (empty input, a failure, a result
+// beyond BrotliEncoderMaxCompressedSize: its "store uncompressed" fall-back).  cc:653.
+bool BrotliCompress(const uint8_t* in, size_t n, uint8_t* out, size_t* size) {
+  const size_t cap = *size, max_out = BrotliEncoderMaxCompressedSize(n);
+  static const bool plain = getenv("FPV_BROTLI_ARENA") && !strcmp(getenv("FPV_BROTLI_ARENA"), "0");
+  if (n > 0 && cap > 0 && !plain) {
+    BrotliArena& a = ThreadArena();
+    if (BrotliEncoderState* st = BrotliEncoderCreateInstance(BrotliArena::Alloc, BrotliArena::Free, &a)) {
+      BrotliEncoderSetParameter(st, BROTLI_PARAM_QUALITY, 1);
+      BrotliEncoderSetParameter(st, BROTLI_PARAM_LGWIN, BROTLI_DEFAULT_WINDOW);
+      BrotliEncoderSetParameter(st, BROTLI_PARAM_MODE, BROTLI_DEFAULT_MODE);
+      BrotliEncoderSetParameter(st, BROTLI_PARAM_SIZE_HINT, (uint32_t)n);
+      size_t avail_in = n, avail_out = cap, total = 0;
+      const uint8_t* next_in = in;
+      uint8_t* next_out = out;
+      const bool ok = BrotliEncoderCompressStream(st, BROTLI_OPERATION_FINISH, &avail_in, &next_in, &avail_out, &next_out, &total) &&
+                      BrotliEncoderIsFinished(st);
+      BrotliEncoderDestroyInstance(st);
+      if (ok && (max_out == 0 || total <= max_out)) {
+        *size = total;
+        return true;
+      }
+    }
+  }
+  *size = cap;
+  return BrotliEncoderCompress(1, BROTLI_DEFAULT_WINDOW, BROTLI_DEFAULT_MODE, n, in, size, out) != 0;
+}
+
 // cc:653: quality 1, default window (22), default mode; one shot per plane.
 // Appends to *out.  The reference first tries a plane-sized output buffer for
 // the low plane and retries with the maximum (cc:661-673); the bytes are the
@@ -118,8 +189,7 @@ bool BrotliAppend(const uint8_t* in, size_t n, std::vector<uint8_t>* out) {
   size_t at = out->size();
   out->resize(at + cap);
   size_t sz = cap;
-  if (!BrotliEncoderCompress(1, BROTLI_DEFAULT_WINDOW, BROTLI_DEFAULT_MODE, n, in,
-                             &sz, out->data() + at)) {
+  if (!BrotliCompress(in, n, out->data() + at, &sz)) {
     out->resize(at);
     return false;
   }
@@ -132,7 +202,8 @@ bool BrotliAppend(const uint8_t* in, size_t n, std::vector<uint8_t>* out) {
 // longer than cap stops with got == cap and returns false.
 bool BrotliInto(const uint8_t* in, size_t size, size_t* pos, uint8_t* dst,
                 size_t cap, size_t* got) {
-  BrotliDecoderState* st = BrotliDecoderCreateInstance(nullptr, nullptr, nullptr);
+  BrotliArena& arena = ThreadArena();  // the decoder's state (ring buffer, trees) in this thread's arena
+  BrotliDecoderState* st = BrotliDecoderCreateInstance(BrotliArena::Alloc, BrotliArena::Free, &arena);
   if (!st) return false;
   size_t avail_in = size - *pos, avail_out = cap;
   const uint8_t* next_in = in + *pos;
@@ -273,7 +344,7 @@ void BuildFrameChunk(const uint8_t* high, const uint8_t* low, const uint8_t* pre
   p[at++] = (uint8_t)((flags & USE_CG) | NO_LOW_BYTES);  // cc:842
   auto brotli = [&](const uint8_t* in, size_t n, size_t cap, const char* what) {
     size_t sz = cap;  // cc:653: quality 1, default window (22), default mode; one shot per plane
-    if (!BrotliEncoderCompress(1, BROTLI_DEFAULT_WINDOW, BROTLI_DEFAULT_MODE, n, in, &sz, p + at)) Fatal("Brotli", what);
+    if (!BrotliCompress(in, n, p + at, &sz)) Fatal("Brotli", what);
     at += sz;
   };
   brotli(preview, npv, cap_pv, "preview plane");

@@ -47,6 +47,9 @@ void Store64(uint64_t v, uint8_t* p);
 void Append32(uint32_t v, std::vector<uint8_t>* out);
 bool OutOfRange(size_t pos, size_t width, size_t size);
 
+// BrotliEncoderCompress(q = 1, default window, default mode) with the encoder's state in a
+// per-thread arena; *size: capacity in, bytes out.  Byte-identical to the library's one-shot call.
+bool BrotliCompress(const uint8_t* in, size_t n, uint8_t* out, size_t* size);
 bool BrotliAppend(const uint8_t* in, size_t n, std::vector<uint8_t>* out);
 bool BrotliInto(const uint8_t* in, size_t size, size_t* pos, uint8_t* dst,
                 size_t cap, size_t* got);

@@ -43,6 +43,9 @@ double fpvc_bench_encode(const uint16_t *frames, size_t distinct, size_t total, 
  * Whole-stream helpers.  encode: Init(delta) + CompressFrame x n + Finish into
  * out (capacity cap); returns the stream size or 0 when it does not fit.
  */
+/* TEST HOOK: 1 when the library's arena-backed Brotli call gives exactly the bytes of libbrotli's
+ * BrotliEncoderCompress(1, default window, default mode) for this input. */
+int fpvc_test_brotli_equivalence(const uint8_t *in, size_t n);
 size_t fpvc_encode_stream(const uint16_t *frames, size_t nframes,
                           const uint16_t *delta_raw, size_t xs, size_t ys,
                           int shift, int big_endian, size_t num_threads,

@@ -371,6 +371,40 @@ def test_failed_session_then_more_sessions_in_one_process(tmp_path):
     assert "injected failure" in out.stdout.split("ERR1", 1)[1].splitlines()[0]
 
 
+def test_brotli_arena_bytes_are_the_librarys():
+    """The host compresses every plane with libbrotli's state in a per-thread arena (round 4: the
+    one-shot entry point's malloc / mmap / munmap per plane made sixteen worker threads queue on
+    the address-space lock).  Same library, same parameters (cc:653: quality 1, default window,
+    default mode), so the bytes must be those of BrotliEncoderCompress itself -- checked here call
+    by call on empty, tiny, constant, random, preview-sized, plane-sized and 16 MB inputs, from
+    several threads at once (each with its own arena)."""
+    import ctypes
+    import threading
+    if not os.path.exists(SHIM):
+        pytest.skip("tests/shim not built")
+    lib = ctypes.CDLL(SHIM)
+    lib.fpvc_test_brotli_equivalence.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    rng = np.random.default_rng(5)
+    smooth = (np.add.outer(np.arange(800) // 3, np.arange(1280) // 5) + rng.integers(0, 3, (800, 1280))).astype(np.uint8).reshape(-1)
+    cases = [np.zeros(0, np.uint8), np.zeros(1, np.uint8), rng.integers(0, 256, 100, dtype=np.uint8), np.zeros(64000, np.uint8),
+             rng.integers(0, 256, 64000, dtype=np.uint8), smooth, rng.integers(0, 256, 1024000, dtype=np.uint8),
+             (rng.integers(0, 4, 1 << 20) * 7).astype(np.uint8), smooth[: 4096 * 100], np.tile(smooth, 16),
+             GOLD["plasma12_le_s4/fpv"].copy()]
+    bad = []
+
+    def run(offset):
+        for k in range(len(cases)):
+            c = np.ascontiguousarray(cases[(k + offset) % len(cases)])
+            if lib.fpvc_test_brotli_equivalence(c.ctypes.data if c.size else None, c.size) != 1:
+                bad.append((offset, c.size))
+    th = [threading.Thread(target=run, args=(i,)) for i in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not bad, bad
+
+
 def test_fuzzed_streams_never_crash(codec):
     """Random byte flips, truncations and splices: every decoder entry either
     succeeds or reports failure; none may crash or read out of bounds."""

@@ -2951,8 +2951,9 @@ static hipError_t predict_impl(const Geom& g, const uint16_t* d_frames,
     const bool lowp = g.shift != 8;
     const uint32_t T = g.tile_threads, lds = g.tile_lds;
     if (ev) hipEventRecord(ev[0], s);
-    if (lowp) k_tile<SWAP, true><<<nframes * g.tile_tiles, T, lds, s>>>(L);
-    else k_tile<SWAP, false><<<nframes * g.tile_tiles, T, lds, s>>>(L);
+    const uint32_t tgrid = (FPV_TILE_PAIR ? (nframes + 1) / 2 : nframes) * g.tile_tiles;
+    if (lowp) k_tile<SWAP, true><<<tgrid, T, lds, s>>>(L);
+    else k_tile<SWAP, false><<<tgrid, T, lds, s>>>(L);
     if (ev) hipEventRecord(ev[1], s);
     if (g.tile_tiles > 64) k_tile_decide<SWAP, true><<<nframes, 1024, 0, s>>>(L);   // many records per frame (large frames)
     else k_tile_decide<SWAP, false><<<nframes, 256, 0, s>>>(L);

@@ -371,6 +371,44 @@ def test_failed_session_then_more_sessions_in_one_process(tmp_path):
     assert "injected failure" in out.stdout.split("ERR1", 1)[1].splitlines()[0]
 
 
+_STATS_SCRIPT = r'''
+import sys, os, ctypes, importlib, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+from conftest import load_package
+load_package()
+synth = importlib.import_module("fpv_amd.synth")
+lib = ctypes.CDLL(sys.argv[2])
+lib.fpvc_bench_encode.restype = ctypes.c_double
+lib.fpvc_bench_encode.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
+                                  ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_double), ctypes.c_size_t]
+fr = np.ascontiguousarray(synth.noise_frames(8, 64, 48, seed=3)).reshape(-1)
+st, nb = (ctypes.c_double * 43)(), ctypes.c_size_t()
+dt = lib.fpvc_bench_encode(fr.ctypes.data, 8, 120, 64, 48, 0, 0, 4, ctypes.byref(nb), st, 43)
+print("STATS", " ".join("%g" % v for v in st))
+'''
+
+
+def test_encoder_stats_per_device(tmp_path):
+    """Encoder::LastStats (extension): frames, batches and, per device of the session, the batches
+    it took and the time its dispatcher waited for it -- what the multi-GPU bench line's e2e_multi
+    reports.  Three devices (the shim), 120 frames in batches of up to 4: the batches are dealt round robin
+    (batch b goes to device b mod 3, cc:1199-1230 is the reference's own distribution axis)."""
+    import subprocess
+    import sys
+    if not os.path.exists(SHIM):
+        pytest.skip("tests/shim not built")
+    script = tmp_path / "stats.py"
+    script.write_text(_STATS_SCRIPT)
+    out = subprocess.run([sys.executable, str(script), os.path.dirname(HERE), SHIM],
+                         env=dict(os.environ, FPV_SHIM_DEVICES="3", FPV_BATCH="4"), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    st = [float(v) for v in [l for l in out.stdout.splitlines() if l.startswith("STATS")][0].split()[1:]]
+    assert st[0] == 120 and st[10] == 3 and 30 <= st[5] <= 120     # (partial batches are flushed when the producer blocks or idles)
+    per_dev = [st[11], st[13], st[15]]
+    assert sum(per_dev) == st[5] and max(per_dev) - min(per_dev) <= 1, per_dev      # round robin
+    assert all(st[12 + 2 * d] >= 0 for d in range(3)) and st[17] == 0               # nothing beyond the session's devices
+
+
 def test_brotli_arena_bytes_are_the_librarys():
     """The host compresses every plane with libbrotli's state in a per-thread arena (round 4: the
     one-shot entry point's malloc / mmap / munmap per plane made sixteen worker threads queue on

@@ -575,6 +575,7 @@ struct Encoder::Impl {
   std::vector<int> gpu_inflight;              // [dev] batches submitted and not yet back
   int gpu_inflight_max = 3;
   std::deque<Task> work_q;                    // Brotli tasks
+  int working = 0;                            // workers inside a Brotli task
   std::deque<Task> copy_q;                    // staging copies (served first)
   struct Prep { int dev; uint32_t slot; };
   std::deque<Prep> prep_q;                    // slots to allocate ahead of need (served before everything)
@@ -838,13 +839,18 @@ struct Encoder::Impl {
     std::unique_lock<std::mutex> l(m);
     for (;;) {
       cv_work.wait(l, [this] { return stop || failed.load() || !work_q.empty() || !copy_q.empty() || !prep_q.empty(); });
-      if (failed.load()) {  // nothing of this session will be emitted any more
-        work_q.clear();
+      if (failed.load()) {
+        // No further batch goes to the GPU.  What is still in work_q belongs to batches that CAME
+        // BACK before the failure -- their planes are valid -- and is compressed and emitted as
+        // usual, so that the stream ends with a clean, deterministic prefix: every frame of every
+        // batch in front of the first one that failed.
         copy_q.clear();
         prep_q.clear();
-        if (stop) return;
-        cv_work.wait_until(l, std::chrono::system_clock::now() + std::chrono::milliseconds(20));
-        continue;
+        if (work_q.empty()) {
+          if (stop) return;
+          cv_work.wait_until(l, std::chrono::system_clock::now() + std::chrono::milliseconds(20));
+          continue;
+        }
       }
       if (!prep_q.empty()) {
         const Prep pr = prep_q.front();
@@ -876,6 +882,7 @@ struct Encoder::Impl {
       }
       Task t = work_q.front();
       work_q.pop_front();
+      working++;
       l.unlock();
       std::vector<uint8_t> chunk;
       const uint64_t tb = stats ? NowNs() : 0;
@@ -885,6 +892,8 @@ struct Encoder::Impl {
       t.b->chunks[t.k].swap(chunk);
       t.b->done[t.k] = 1;
       DrainLocked(l);
+      working--;
+      if (failed.load()) cv_producer.notify_all();  // Finish waits for the work that was in flight at the failure
     }
   }
 
@@ -1110,7 +1119,10 @@ void Encoder::Finish(Callback callback, void* payload) {
           l.lock();
         }
       }
-      s.cv_producer.wait(l, [&s] { return (s.inflight == 0 && s.emit_q.empty()) || s.failed.load(); });
+      // (after a failure: until the batches that came back before it have been compressed and emitted)
+      s.cv_producer.wait(l, [&s] {
+        return (s.inflight == 0 && s.emit_q.empty()) || (s.failed.load() && s.work_q.empty() && s.working == 0 && !s.emitting);
+      });
     }
     s.StopThreads();
   }

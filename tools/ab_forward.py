@@ -42,7 +42,11 @@ for spec in libs:
     p = pkg.Predictor(XS, YS, shift, False, max_batch=N)
     if not args.nodelta:
         p.set_delta_raw(base[0])
-    out = shared_out = shared_out or p.alloc_outputs(N)   # every variant writes the SAME buffers: HBM
+    if shared_out is None:
+        shared_out = p.alloc_outputs(N)
+        if os.environ.get("FPV_AB_ILV"):                   # -DFPV_TILE_ILV=1 builds write both planes into `high`: 2 npix per frame (+ slack)
+            shared_out = (torch.empty((2 * N + 1, p.npix), dtype=torch.uint8, device="cuda"),) + shared_out[1:]
+    out = shared_out                                       # every variant writes the SAME buffers: HBM
     for _ in range(3):                                     # placement alone moves the time by several percent
         p.predict(fr, out=out)
     torch.cuda.synchronize()

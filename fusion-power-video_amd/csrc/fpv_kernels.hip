@@ -2899,6 +2899,7 @@ static hipError_t predict_impl(const Geom& g, const uint16_t* d_frames,
     TileArgs& a = L.g;
     a.xs = g.xs; a.ys = g.ys; a.npix = g.npix; a.pw = g.pw; a.npv = g.npv;
     a.ncs = g.xs / 8; a.groups = g.tile8_groups; a.tiles = g.tile8_tiles; a.nitems = a.groups * a.ncs;
+    a.ncs_rcp = ((1u << 20) + a.ncs - 1u) / a.ncs;
     a.shift = (uint32_t)g.shift; a.nframes = nframes; a.with_delta = (uint32_t)with_delta;
     a.in_pitch = a.out_pitch = g.npix;
     a.xs15 = g.xs % 15u; a.xs31 = g.xs % 31u; a.c31 = (g.xs + 1u) % 31u; a.ncg = g.ncg;
@@ -2937,6 +2938,7 @@ static hipError_t predict_impl(const Geom& g, const uint16_t* d_frames,
     TileArgs& a = L.g;
     a.xs = g.xs; a.ys = g.ys; a.npix = g.npix; a.pw = g.pw; a.npv = g.npv;
     a.ncs = g.xs / 16; a.groups = g.tile_groups; a.tiles = g.tile_tiles; a.nitems = a.groups * a.ncs;
+    a.ncs_rcp = ((1u << 20) + a.ncs - 1u) / a.ncs;
     a.shift = (uint32_t)g.shift; a.nframes = nframes; a.with_delta = (uint32_t)with_delta;
     a.in_pitch = a.out_pitch = g.npix;
     a.xs15 = g.xs % 15u; a.xs31 = g.xs % 31u; a.c31 = (g.xs + 1u) % 31u; a.ncg = g.ncg;
@@ -2951,7 +2953,11 @@ static hipError_t predict_impl(const Geom& g, const uint16_t* d_frames,
     const bool lowp = g.shift != 8;
     const uint32_t T = g.tile_threads, lds = g.tile_lds;
     if (ev) hipEventRecord(ev[0], s);
-    const uint32_t tgrid = (FPV_TILE_PAIR ? (nframes + 1) / 2 : nframes) * g.tile_tiles;
+#if FPV_TILE_PAIR || FPV_TILE_XGROUP > 1  // experiments: a flat grid
+    const dim3 tgrid((FPV_TILE_PAIR ? (nframes + 1) / 2 : nframes) * g.tile_tiles);
+#else
+    const dim3 tgrid(g.tile_tiles, nframes);  // x fastest = memory order; nframes <= 65535 (create_impl)
+#endif
     if (lowp) k_tile<SWAP, true><<<tgrid, T, lds, s>>>(L);
     else k_tile<SWAP, false><<<tgrid, T, lds, s>>>(L);
     if (ev) hipEventRecord(ev[1], s);

@@ -2920,7 +2920,7 @@ static hipError_t predict_impl(const Geom& g, const uint16_t* d_frames,
       if (g.tile8_rows == 8) { if (lowp) K<SWAP, true, 8><<<GRID, T, lds, s>>>(L); else K<SWAP, false, 8><<<GRID, T, lds, s>>>(L); } \
       else { if (lowp) K<SWAP, true, 4><<<GRID, T, lds, s>>>(L); else K<SWAP, false, 4><<<GRID, T, lds, s>>>(L); } \
     } while (0)
-    FPV_T8(k_tile8, grid);
+    FPV_T8(k_tile8, dim3(g.tile8_tiles, nframes));  // x fastest = memory order
     if (ev) hipEventRecord(ev[1], s);
     const bool frame_big = g.tile8_frame_big;  // FPV_FRAME8_BIG (experiments / tests): 1024 threads whatever the size
     if (g.tile8_tiles > 64 || frame_big) k_frame8<SWAP, true><<<nframes, 1024, 0, s>>>(L);   // many records per frame (large frames)

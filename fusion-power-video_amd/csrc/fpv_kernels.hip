@@ -2675,6 +2675,7 @@ bool make_geom(uint32_t xs, uint32_t ys, int shift, int big_endian, Geom* g,
         g->tile_threads = T;
         g->tile_tiles = tiles;
         g->tile_lds = tile_lds_bytes(G, ncs);
+        g->tile_decide_big = getenv("FPV_DECIDE_BIG") != nullptr;
       }
     }
   }
@@ -2961,7 +2962,7 @@ static hipError_t predict_impl(const Geom& g, const uint16_t* d_frames,
     if (lowp) k_tile<SWAP, true><<<tgrid, T, lds, s>>>(L);
     else k_tile<SWAP, false><<<tgrid, T, lds, s>>>(L);
     if (ev) hipEventRecord(ev[1], s);
-    if (g.tile_tiles > 64) k_tile_decide<SWAP, true><<<nframes, 1024, 0, s>>>(L);   // many records per frame (large frames)
+    if (g.tile_tiles > 64 || g.tile_decide_big) k_tile_decide<SWAP, true><<<nframes, 1024, 0, s>>>(L);   // many records per frame (large frames)
     else k_tile_decide<SWAP, false><<<nframes, 256, 0, s>>>(L);
     if (ev) hipEventRecord(ev[2], s);
     const uint32_t rgrid = std::min<uint32_t>(nframes * g.tile_tiles, device_cus() * std::max(1u, 2048u / T));

@@ -79,6 +79,9 @@ def _declare_hip(lib):
     lib.fpvhip_debug_counters.argtypes = [vp, c.POINTER(c.c_uint32), u32]
     lib.fpvhip_inverse_pass_stats.restype = i32
     lib.fpvhip_inverse_pass_stats.argtypes = [vp, c.POINTER(c.c_uint32), i32]
+    if hasattr(lib, "fpvhip_forward_tile_shape"):
+        lib.fpvhip_forward_tile_shape.restype = i32
+        lib.fpvhip_forward_tile_shape.argtypes = [vp, c.POINTER(u32)]
     if hasattr(lib, "fpvhip_debug_set_chain_mask"):
         lib.fpvhip_debug_set_chain_mask.restype = i32
         lib.fpvhip_debug_set_chain_mask.argtypes = [vp, u32]
@@ -239,6 +242,12 @@ class Predictor:
     def set_chain_mask(self, value):
         """Overwrites the three-wave inverse kernel's per-CU "SIMD taken" words (0: all free)."""
         self._check(self.lib.fpvhip_debug_set_chain_mask(self.ctx, value), "debug_set_chain_mask")
+
+    def forward_tile_shape(self):
+        """(groups per tile, threads per workgroup, tiles per frame, log2 column blocks) of the tile pass."""
+        out = (ctypes.c_uint32 * 4)()
+        self._check(self.lib.fpvhip_forward_tile_shape(self.ctx, out), "forward_tile_shape")
+        return tuple(out)
 
     def forward_kernel_names(self):
         """The three launches of one forward batch, in the order of time_predict(per_kernel=True)."""

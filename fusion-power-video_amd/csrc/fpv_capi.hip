@@ -764,6 +764,14 @@ const char* fpvhip_forward_kernel_names(fpvhip_ctx* c) {
   return c->g.tile_ok ? "k_tile,k_tile_decide,k_tile_finish" : "k_stream,k_redo_decide,k_redo_stream";
 }
 
+int fpvhip_forward_tile_shape(fpvhip_ctx* c, uint32_t out[4]) {
+  if (!c || !out) return fail(c, "bad arguments");
+  out[0] = out[1] = out[2] = out[3] = 0;
+  if (c->g.fwd_ok && c->g.tile8_ok) { out[0] = c->g.tile8_groups; out[1] = c->g.tile8_threads; out[2] = c->g.tile8_tiles; }
+  else if (c->g.fwd_ok && c->g.tile_ok) { out[0] = c->g.tile_groups; out[1] = c->g.tile_threads; out[2] = c->g.tile_tiles; out[3] = c->g.tile_lsplit; }
+  return 0;
+}
+
 const char* fpvhip_inverse_kernel_name(fpvhip_ctx* c, uint32_t nframes) {
   if (!c) return "";
   hipSetDevice(c->device);

@@ -226,11 +226,15 @@ int fpvhip_inverse_pass_stats(fpvhip_ctx *ctx, uint32_t *out, int reset);
  * ("k_inverse_trio", "k_inverse_spec", "k_inverse_fast", "k_inverse"). */
 const char *fpvhip_inverse_kernel_name(fpvhip_ctx *ctx, uint32_t nframes);
 /* Diagnostics: the three launches of one forward batch on this context, comma separated
- * ("k_tile8,k_frame8,k_redo8" for round 4's tile pass, "k_tile,k_tile_decide,k_tile_finish" for
- * round 3's (FPV_FORWARD=tile16, widths beyond 8192), "k_stream,k_redo_decide,k_redo_stream" for
- * geometries that keep the streaming kernels): the order of kernel_ms[] of
+ * ("k_tile,k_tile_decide,k_tile_finish" for the tile pass, "k_tile8,k_frame8,k_redo8" for its
+ * 8-pixel variant (FPV_FORWARD=tile8), "k_stream,k_redo_decide,k_redo_stream" for geometries
+ * that keep the streaming kernels): the order of kernel_ms[] of
  * fpvhip_time_predict_device. */
 const char *fpvhip_forward_kernel_names(fpvhip_ctx *ctx);
+/* Diagnostics: the shape of the tile pass on this context: out[0] = 4-row groups per tile,
+ * out[1] = threads per workgroup, out[2] = tiles per frame, out[3] = log2 of the column blocks per
+ * row block (wide frames; 0 = whole-width tiles).  All zero when the streaming kernels are taken. */
+int fpvhip_forward_tile_shape(fpvhip_ctx *ctx, uint32_t out[4]);
 /* Diagnostics / recovery: the three-wave inverse kernel keeps one word per CU of "SIMDs that
  * already run some frame's chain wave" in device memory (a placement hint: results never depend
  * on it; DecompressImage's loop cc:326-344 has no such notion).  A kernel killed in mid-flight

@@ -85,6 +85,7 @@ int fpvhip_trim(fpvhip_ctx *c) { (void)c; return 0; }
 const char *fpvhip_inverse_kernel_name(fpvhip_ctx *c, uint32_t n) { (void)c; (void)n; return "oracle"; }
 const char *fpvhip_forward_kernel_names(fpvhip_ctx *c) { (void)c; return "oracle,oracle,oracle"; }
 int fpvhip_debug_set_chain_mask(fpvhip_ctx *c, uint32_t v) { (void)c; (void)v; return 0; }
+int fpvhip_forward_tile_shape(fpvhip_ctx *c, uint32_t out[4]) { (void)c; out[0] = out[1] = out[2] = out[3] = 0; return 0; }
 int fpvhip_debug_counters(fpvhip_ctx *c, uint32_t *out, uint32_t n) { (void)c; (void)out; (void)n; return -1; }
 double fpvhip_slot_elapsed_ms(fpvhip_ctx *c, uint32_t slot) { (void)c; (void)slot; return 0.0; }
 double fpvhip_time_copy_device(void *d, const void *s, size_t b, void *st, int it) { (void)d; (void)s; (void)b; (void)st; (void)it; return -1.0; }

@@ -90,6 +90,7 @@ def test_partial_batches_reuse_workspace(fpv, synth, oracle):
 @pytest.mark.parametrize("env", [{"FPV_FORWARD": "stream", "FPV_STRIP_ROWS": "4"}, {"FPV_FORWARD": "stream", "FPV_STRIP_ROWS": "80", "FPV_STRIP_MAJOR": "0"},
                                  {"FPV_FORWARD": "stream", "FPV_STRIP_ROWS": "12", "FPV_WAVES_PER_CU": "2"}, {"FPV_FORWARD": "stream"},
                                  {"FPV_TILE_GROUPS": "1"}, {"FPV_TILE_GROUPS": "7"}, {"FPV_TILE_GROUPS": "50"}, {"FPV_FORWARD": "tile16"},
+                                 {"FPV_TILE_FGROUP": "2"}, {"FPV_TILE_FGROUP": "4", "FPV_TILE_GROUPS": "7"}, {"FPV_TILE_FGROUP": "1", "FPV_TILE_GROUPS": "1"},
                                  {"FPV_FORWARD": "tile8"}, {"FPV_FORWARD": "tile8", "FPV_FRAME8_BIG": "1"},
                                  {"FPV_FORWARD": "tile8", "FPV_TILE8_GROUPS": "1"}, {"FPV_FORWARD": "tile8", "FPV_TILE8_GROUPS": "2"},
                                  {"FPV_FORWARD": "tile8", "FPV_TILE8_GROUPS": "5"}, {"FPV_FORWARD": "tile8", "FPV_TILE8_GROUPS": "50"},
@@ -112,6 +113,40 @@ def test_alternate_kernel_paths(fpv, synth, oracle, env):
         fr = np.concatenate([synth.plasma_frames(3, 320, 200, bits=12, seed=5),
                              (synth.noise_frames(3, 320, 200, seed=6) >> 4)])
         _run_case(fpv, oracle, fr, 320, 200, 4, False, fr[0])
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("xs,ys,env", [
+    (512, 40, {"FPV_TILE_SPLIT": "1"}), (512, 40, {"FPV_TILE_SPLIT": "2", "FPV_TILE_GROUPS": "3"}), (512, 36, {"FPV_TILE_SPLIT": "3"}),
+    (1024, 28, {"FPV_TILE_SPLIT": "1", "FPV_TILE_GROUPS": "2"}), (1280, 48, {"FPV_TILE_SPLIT": "2"}), (1920, 32, {"FPV_TILE_SPLIT": "1"}),
+    (4096, 40, {"FPV_TILE_SPLIT": "1"}), (4096, 24, {"FPV_TILE_FGROUP": "2"}), (4096, 24, {"FPV_TILE_SPLIT": "3", "FPV_TILE_GROUPS": "1", "FPV_TILE_FGROUP": "1"}),
+    (6144, 20, {"FPV_TILE_SPLIT": "2"}), (8192, 12, {"FPV_TILE_SPLIT": "4"})])
+def test_column_block_tiles(fpv, synth, oracle, xs, ys, env):
+    """Wide frames: the tile pass cuts a row block into column blocks (a tile = 4 G rows of
+    xs >> lsplit pixels) and fetches what lies left of a block from global memory -- in column block
+    0 that is the end of the row above, the reference's flat neighbourhood.  Forced here on narrow
+    frames too (FPV_TILE_SPLIT), with tile heights that leave a partial last row block, and together with
+    the order large frames take (FPV_TILE_FGROUP: groups of 2^k frames walked tile by tile; the last group
+    is short here); noise (the CG decision flips, frames are redone) and smooth frames, with and without a
+    delta frame."""
+    import os
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        p = fpv.Predictor(xs, ys, 4, False, max_batch=1)
+        groups, threads, tiles, lsplit = p.forward_tile_shape()
+        p.close()
+        want = int(env.get("FPV_TILE_SPLIT", 0))   # off by default (measured: no gain on wide frames, a loss on narrow ones)
+        assert lsplit == want and groups * ((xs // 16) >> lsplit) <= threads, (groups, threads, tiles, lsplit)
+        assert tiles == -(-ys // (4 * groups)) << lsplit
+        fr = np.concatenate([synth.plasma_frames(3, xs, ys, bits=12, seed=5), (synth.noise_frames(3, xs, ys, seed=6) >> 4)])
+        _run_case(fpv, oracle, fr, xs, ys, 4, False, fr[0])
+        _run_case(fpv, oracle, fr[1:5], xs, ys, 4, False, None)
     finally:
         for k, v in old.items():
             if v is None:

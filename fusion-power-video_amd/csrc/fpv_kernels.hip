@@ -2968,7 +2968,7 @@ static hipError_t predict_impl(const Geom& g, const uint16_t* d_frames,
     a.lsplit = g.tile_lsplit;
     a.lfgroup = g.tile_lfgroup;
     if (a.lfgroup && !g.tile_lfgroup_fixed)  // no larger than the batch needs (a group's unused frame slots are workgroups that leave at once)
-      while (a.lfgroup > 4 && (1u << (a.lfgroup - 1)) >= nframes) a.lfgroup--;
+      while (a.lfgroup > 1 && (1u << (a.lfgroup - 1)) >= nframes) a.lfgroup--;  // (the Encoder's batches of such frames are 8 frames)
     a.ncs = (g.xs / 16) >> a.lsplit; a.groups = g.tile_groups; a.tiles = g.tile_tiles; a.nitems = a.groups * a.ncs;
     a.ncs_rcp = ((1u << 20) + a.ncs - 1u) / a.ncs;
     a.shift = (uint32_t)g.shift; a.nframes = nframes; a.with_delta = (uint32_t)with_delta;

@@ -244,7 +244,7 @@ class Predictor:
         self._check(self.lib.fpvhip_debug_set_chain_mask(self.ctx, value), "debug_set_chain_mask")
 
     def forward_tile_shape(self):
-        """(groups per tile, threads per workgroup, tiles per frame, log2 column blocks) of the tile pass."""
+        """(groups per tile, threads per workgroup, tiles per frame, log2 frames per group) of the tile pass."""
         out = (ctypes.c_uint32 * 4)()
         self._check(self.lib.fpvhip_forward_tile_shape(self.ctx, out), "forward_tile_shape")
         return tuple(out)

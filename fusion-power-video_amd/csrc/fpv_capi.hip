@@ -768,7 +768,7 @@ int fpvhip_forward_tile_shape(fpvhip_ctx* c, uint32_t out[4]) {
   if (!c || !out) return fail(c, "bad arguments");
   out[0] = out[1] = out[2] = out[3] = 0;
   if (c->g.fwd_ok && c->g.tile8_ok) { out[0] = c->g.tile8_groups; out[1] = c->g.tile8_threads; out[2] = c->g.tile8_tiles; }
-  else if (c->g.fwd_ok && c->g.tile_ok) { out[0] = c->g.tile_groups; out[1] = c->g.tile_threads; out[2] = c->g.tile_tiles; out[3] = c->g.tile_lsplit; }
+  else if (c->g.fwd_ok && c->g.tile_ok) { out[0] = c->g.tile_groups; out[1] = c->g.tile_threads; out[2] = c->g.tile_tiles; out[3] = c->g.tile_lfgroup; }
   return 0;
 }
 

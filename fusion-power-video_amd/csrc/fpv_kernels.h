@@ -34,7 +34,6 @@ struct Geom {
   uint32_t tile8_ok, tile8_rows, tile8_groups, tile8_threads, tile8_tiles, tile8_lds, tile8_frame_big;
   uint32_t tile_lfgroup;     // log2 of the frames per group the tile pass walks tile by tile (large frames; 0: frame by frame)
   uint32_t tile_lfgroup_fixed;  // FPV_TILE_FGROUP given: not shortened to the batch
-  uint32_t tile_lsplit;      // log2 of the column blocks per row block of the tile pass (wide frames)
   uint32_t tile_decide_big;  // FPV_DECIDE_BIG (experiments / tests): k_tile_decide with 1024 threads whatever the size
   uint32_t nd, ncg;             // sample counts of the two heuristics
   uint32_t ring;                // inverse kernel: LDS ring size (power of two)

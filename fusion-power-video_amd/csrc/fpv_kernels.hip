@@ -2657,23 +2657,16 @@ bool make_geom(uint32_t xs, uint32_t ys, int shift, int big_endian, Geom* g,
   // a 4-row group (the row above a tile is recomputed: 1 / (4 G) more loads).  Widths that are
   // not multiples of 64 or beyond 16 K pixels keep the streaming kernels.
   {
-    // FPV_TILE_SPLIT=<log2> (experiments, tests): a tile is a COLUMN BLOCK of 4 G rows (xs >> lsplit pixels
-    // wide; what lies left of it comes from global memory, four pixels per row, fetched by the thread of the
-    // group's first segment).  Built for wide frames -- at 4096 pixels a whole-width tile of a 512-thread
-    // workgroup is 8 rows, one row in eight a halo row -- and measured: no gain there (0.9405 against 0.9408 ms
-    // per 60 frames of 4096x4096; what those frames wait for is the delta frame, see tile_lfgroup), a loss
-    // on narrower ones (1280x800 +4.6 %: shorter contiguous runs).  Off by default.
-    const uint32_t ncs_full = xs / 16;
-    uint32_t lsplit = 0;
-    if (const char* e = getenv("FPV_TILE_SPLIT")) {
-      const uint32_t want = (uint32_t)atoi(e);
-      if (want <= 4 && (ncs_full & ((1u << want) - 1u)) == 0 && ((ncs_full >> want) & 3u) == 0 && (ncs_full >> want) >= 4) lsplit = want;
-    }
-    const uint32_t ncs = ncs_full >> lsplit;
+    // (Column-block tiles -- half the width, twice the rows, what lies left of a block fetched from global
+    // memory -- were built for wide frames, where a whole-width tile of a 512-thread workgroup is 8 rows and one
+    // row in eight a halo row; bit-exact, and no faster at 4096x4096 (0.9405 against 0.9408 ms per 60 frames:
+    // what those frames wait for is the delta frame, see tile_lfgroup), 3-5 % slower on narrower frames, and
+    // their hooks cost the default shape 0.35 %: taken out again, commit 16feb86 has them.)
+    const uint32_t ncs = xs / 16;
     // Workgroup sizes that fill the CU's wave slots evenly at this kernel's register budget (16
     // waves per CU): 512 threads where that gives at least 2 groups, else 1024 (measured at
     // 1280x800: G = 6 / 512 threads 0.72 ms, G = 4 / 320 threads 0.88, G = 8 / 640 threads 1.0;
-    // at 4096x4096 with whole-width tiles: G = 2 / 512 threads 0.895 ms per 60 frames, G = 4 / 1024 threads 0.965).
+    // at 4096x4096: G = 2 / 512 threads 0.895 ms per 60 frames, G = 4 / 1024 threads 0.965).
     uint32_t G = ncs ? 512u / ncs : 0;
     if (G < 2 && ncs) G = 1024u / ncs;
     if (const char* e = getenv("FPV_TILE_GROUPS")) G = std::max(1u, (uint32_t)atoi(e));
@@ -2683,13 +2676,12 @@ bool make_geom(uint32_t xs, uint32_t ys, int shift, int big_endian, Geom* g,
     g->tile_ok = 0;
     if ((xs & 63) == 0 && ncs <= 1024 && G >= 1 && !(fwd && fwd[0] == 's')) {
       const uint32_t T = std::max(256u, round_up(G * ncs, 64));  // the finishing path wants 256 threads
-      const uint32_t tiles = ((ys + 4 * G - 1) / (4 * G)) << lsplit;
+      const uint32_t tiles = (ys + 4 * G - 1) / (4 * G);
       if (T <= 1024 && tiles <= 65535) {
         g->tile_ok = 1;
         g->tile_groups = G;
         g->tile_threads = T;
         g->tile_tiles = tiles;
-        g->tile_lsplit = lsplit;
         // Large frames: the batch is walked in groups of 64 frames, TILE BY TILE inside a group (the frame of the
         // group fastest), so that a tile's delta bytes are fetched once per group.  Walked frame by frame -- the
         // memory order, best while the delta planes (2 bytes per pixel) stay in the L2s -- a 4096x4096 batch
@@ -2700,7 +2692,7 @@ bool make_geom(uint32_t xs, uint32_t ys, int shift, int big_endian, Geom* g,
         g->tile_lfgroup = 2ull * xs * ys > FPV_TILE_FGROUP_MIN_BYTES ? 6u : 0u;
         if (const char* e = getenv("FPV_TILE_FGROUP")) g->tile_lfgroup = std::min(10u, (uint32_t)atoi(e));
         g->tile_lfgroup_fixed = getenv("FPV_TILE_FGROUP") != nullptr;
-        g->tile_lds = tile_lds_bytes(G, ncs, lsplit ? 1u : 0u);
+        g->tile_lds = tile_lds_bytes(G, ncs);
         g->tile_decide_big = getenv("FPV_DECIDE_BIG") != nullptr;
       }
     }
@@ -2925,7 +2917,7 @@ static hipError_t predict_impl(const Geom& g, const uint16_t* d_frames,
     TileLaunch L;
     TileArgs& a = L.g;
     a.xs = g.xs; a.ys = g.ys; a.npix = g.npix; a.pw = g.pw; a.npv = g.npv;
-    a.lsplit = 0; a.lfgroup = 0;
+    a.lfgroup = 0;
     a.ncs = g.xs / 8; a.groups = g.tile8_groups; a.tiles = g.tile8_tiles; a.nitems = a.groups * a.ncs;
     a.ncs_rcp = ((1u << 20) + a.ncs - 1u) / a.ncs;
     a.shift = (uint32_t)g.shift; a.nframes = nframes; a.with_delta = (uint32_t)with_delta;
@@ -2965,11 +2957,10 @@ static hipError_t predict_impl(const Geom& g, const uint16_t* d_frames,
     TileLaunch L;
     TileArgs& a = L.g;
     a.xs = g.xs; a.ys = g.ys; a.npix = g.npix; a.pw = g.pw; a.npv = g.npv;
-    a.lsplit = g.tile_lsplit;
     a.lfgroup = g.tile_lfgroup;
     if (a.lfgroup && !g.tile_lfgroup_fixed)  // no larger than the batch needs (a group's unused frame slots are workgroups that leave at once)
       while (a.lfgroup > 1 && (1u << (a.lfgroup - 1)) >= nframes) a.lfgroup--;  // (the Encoder's batches of such frames are 8 frames)
-    a.ncs = (g.xs / 16) >> a.lsplit; a.groups = g.tile_groups; a.tiles = g.tile_tiles; a.nitems = a.groups * a.ncs;
+    a.ncs = g.xs / 16; a.groups = g.tile_groups; a.tiles = g.tile_tiles; a.nitems = a.groups * a.ncs;
     a.ncs_rcp = ((1u << 20) + a.ncs - 1u) / a.ncs;
     a.shift = (uint32_t)g.shift; a.nframes = nframes; a.with_delta = (uint32_t)with_delta;
     a.in_pitch = a.out_pitch = g.npix;

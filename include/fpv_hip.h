@@ -232,8 +232,9 @@ const char *fpvhip_inverse_kernel_name(fpvhip_ctx *ctx, uint32_t nframes);
  * fpvhip_time_predict_device. */
 const char *fpvhip_forward_kernel_names(fpvhip_ctx *ctx);
 /* Diagnostics: the shape of the tile pass on this context: out[0] = 4-row groups per tile,
- * out[1] = threads per workgroup, out[2] = tiles per frame, out[3] = log2 of the column blocks per
- * row block (wide frames; 0 = whole-width tiles).  All zero when the streaming kernels are taken. */
+ * out[1] = threads per workgroup, out[2] = tiles per frame, out[3] = log2 of the frames per group
+ * that large frames are walked in tile by tile (0: frame by frame, the memory order).  All zero
+ * when the streaming kernels are taken. */
 int fpvhip_forward_tile_shape(fpvhip_ctx *ctx, uint32_t out[4]);
 /* Diagnostics / recovery: the three-wave inverse kernel keeps one word per CU of "SIMDs that
  * already run some frame's chain wave" in device memory (a placement hint: results never depend

@@ -76,16 +76,14 @@ while time.time() - t0 < budget:
     os.environ["FPV_INVERSE"] = str(rng.choice(["spec", "trio", "auto", "fast"], p=[0.4, 0.4, 0.1, 0.1]))  # read per launch
     # forward path (read when the context is created): the tile pass with a random tile height where the
     # width allows it (multiples of 64), now and then the streaming kernels instead
-    for k in ("FPV_TILE_GROUPS", "FPV_FORWARD", "FPV_TILE8_GROUPS", "FPV_TILE8_ROWS", "FPV_TILE_SPLIT", "FPV_TILE_FGROUP"):
+    for k in ("FPV_TILE_GROUPS", "FPV_FORWARD", "FPV_TILE8_GROUPS", "FPV_TILE8_ROWS", "FPV_TILE_FGROUP"):
         os.environ.pop(k, None)
     r = int(rng.integers(0, 12))
     if r == 0:
         os.environ["FPV_FORWARD"] = "stream"
     elif r < 4:     # the tile pass (16 pixels per lane) at a random tile height (default height otherwise),
         os.environ["FPV_TILE_GROUPS"] = str(int(rng.integers(1, 24)))
-        if rng.integers(0, 2):   # ... as column blocks (taken where the width divides), in groups of frames walked tile by tile
-            os.environ["FPV_TILE_SPLIT"] = str(int(rng.integers(0, 5)))
-        if rng.integers(0, 2):
+        if rng.integers(0, 2):   # ... in groups of frames walked tile by tile (the order large frames take)
             os.environ["FPV_TILE_FGROUP"] = str(int(rng.integers(0, 4)))
     elif r < 8:     # round 4's variant (8 pixels per lane): 4 or 8 rows per thread, random tile height
         os.environ["FPV_FORWARD"] = "tile8"

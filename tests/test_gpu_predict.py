@@ -121,32 +121,26 @@ def test_alternate_kernel_paths(fpv, synth, oracle, env):
                 os.environ[k] = v
 
 
-@pytest.mark.parametrize("xs,ys,env", [
-    (512, 40, {"FPV_TILE_SPLIT": "1"}), (512, 40, {"FPV_TILE_SPLIT": "2", "FPV_TILE_GROUPS": "3"}), (512, 36, {"FPV_TILE_SPLIT": "3"}),
-    (1024, 28, {"FPV_TILE_SPLIT": "1", "FPV_TILE_GROUPS": "2"}), (1280, 48, {"FPV_TILE_SPLIT": "2"}), (1920, 32, {"FPV_TILE_SPLIT": "1"}),
-    (4096, 40, {"FPV_TILE_SPLIT": "1"}), (4096, 24, {"FPV_TILE_FGROUP": "2"}), (4096, 24, {"FPV_TILE_SPLIT": "3", "FPV_TILE_GROUPS": "1", "FPV_TILE_FGROUP": "1"}),
-    (6144, 20, {"FPV_TILE_SPLIT": "2"}), (8192, 12, {"FPV_TILE_SPLIT": "4"})])
-def test_column_block_tiles(fpv, synth, oracle, xs, ys, env):
-    """Wide frames: the tile pass cuts a row block into column blocks (a tile = 4 G rows of
-    xs >> lsplit pixels) and fetches what lies left of a block from global memory -- in column block
-    0 that is the end of the row above, the reference's flat neighbourhood.  Forced here on narrow
-    frames too (FPV_TILE_SPLIT), with tile heights that leave a partial last row block, and together with
-    the order large frames take (FPV_TILE_FGROUP: groups of 2^k frames walked tile by tile; the last group
-    is short here); noise (the CG decision flips, frames are redone) and smooth frames, with and without a
-    delta frame."""
+@pytest.mark.parametrize("xs,ys,n,env,want", [
+    (512, 40, 6, {"FPV_TILE_FGROUP": "2"}, 2), (1280, 48, 5, {"FPV_TILE_FGROUP": "3", "FPV_TILE_GROUPS": "5"}, 3), (4096, 24, 6, {"FPV_TILE_FGROUP": "1"}, 1),
+    (4096, 1032, 3, {}, 6), (2048, 1536, 2, {}, 0)])
+def test_large_frame_order(fpv, synth, oracle, xs, ys, n, env, want):
+    """Frames whose delta planes pass 8 MB are walked in groups of frames TILE BY TILE (the frame of the
+    group fastest; grid = (tiles << k, groups)) instead of frame by frame; forced here on small frames
+    too (FPV_TILE_FGROUP=k) with batches that leave the last group short -- its empty slots are
+    workgroups that leave at once -- and with a partial last tile.  Noise (the CG decision flips,
+    frames are redone) and smooth frames, with and without a delta frame."""
     import os
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
         p = fpv.Predictor(xs, ys, 4, False, max_batch=1)
-        groups, threads, tiles, lsplit = p.forward_tile_shape()
+        groups, threads, tiles, lfgroup = p.forward_tile_shape()
         p.close()
-        want = int(env.get("FPV_TILE_SPLIT", 0))   # off by default (measured: no gain on wide frames, a loss on narrow ones)
-        assert lsplit == want and groups * ((xs // 16) >> lsplit) <= threads, (groups, threads, tiles, lsplit)
-        assert tiles == -(-ys // (4 * groups)) << lsplit
-        fr = np.concatenate([synth.plasma_frames(3, xs, ys, bits=12, seed=5), (synth.noise_frames(3, xs, ys, seed=6) >> 4)])
+        assert lfgroup == want and tiles == -(-ys // (4 * groups)) and groups * (xs // 16) <= threads, (groups, threads, tiles, lfgroup)
+        fr = np.concatenate([synth.plasma_frames(n - n // 2, xs, ys, bits=12, seed=5), (synth.noise_frames(n // 2, xs, ys, seed=6) >> 4)])
         _run_case(fpv, oracle, fr, xs, ys, 4, False, fr[0])
-        _run_case(fpv, oracle, fr[1:5], xs, ys, 4, False, None)
+        _run_case(fpv, oracle, fr[1:], xs, ys, 4, False, None)
     finally:
         for k, v in old.items():
             if v is None:

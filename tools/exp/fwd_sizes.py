@@ -17,11 +17,9 @@ for xs, ys, n, shift, bits in cases:
     # the default (the tile pass, 16 pixels per lane), round 4's variant (8 pixels per lane; R = 4, R = 8, shorter tiles), the streaming kernels
     envs = ({}, {"FPV_FORWARD": "tile8"}, {"FPV_FORWARD": "tile8", "FPV_TILE8_ROWS": "8"}, {"FPV_FORWARD": "tile8", "FPV_TILE8_GROUPS": "3"},
             {"FPV_FORWARD": "stream"})
-    if len(sys.argv) > 1 and sys.argv[1] == "split":   # column-block tiles (wide frames by default): whole-width tiles against 2 / 4 blocks
-        envs = ({}, {"FPV_TILE_SPLIT": "0"}, {"FPV_TILE_SPLIT": "1"}, {"FPV_TILE_SPLIT": "2"}, {"FPV_FORWARD": "tile8"}, {"FPV_FORWARD": "stream"})
-    if len(sys.argv) > 1 and sys.argv[1] == "order":   # groups of F frames walked tile by tile (large frames by default) x column blocks
+    if len(sys.argv) > 1 and sys.argv[1] == "order":   # groups of F frames walked tile by tile (large frames by default) 
         envs = ({}, {"FPV_TILE_FGROUP": "0"}, {"FPV_TILE_FGROUP": "5"}, {"FPV_TILE_FGROUP": "6"}, {"FPV_TILE_FGROUP": "7"}, {"FPV_TILE_FGROUP": "8"},
-                {"FPV_TILE_FGROUP": "7", "FPV_TILE_SPLIT": "1"}, {"FPV_FORWARD": "stream"})
+                {"FPV_FORWARD": "stream"})
     for env in envs:
         os.environ.update(env)
         p = pkg.Predictor(xs, ys, shift, False, max_batch=n); p.set_delta_raw(base[0])

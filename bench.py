@@ -282,6 +282,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--frames", type=int, default=NFRAMES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-large", action="store_true", help="skip the 4096x4096 figure (large_frames)")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--placement-survey", type=int, default=3,
                     help="AFTER the measurement: further buffer sets allocated one at a time, timed and freed, reported "
@@ -550,6 +551,56 @@ def main():
         pred.predict(d_frames, out=out)   # leave the plasma planes in `out`
         torch.cuda.synchronize()
 
+    # BASELINE config 3's frame size (4096x4096 16-bit; its 1000 frames are sharded over eight GPUs, 60 of
+    # them here): the delta planes (33.5 MB) do not stay in the L2s, so the tile pass walks groups of 64
+    # frames tile by tile instead of frame by frame (fpv_kernels.hip, tile_lfgroup) -- both orders timed.
+    large = None
+    if rank == 0 and not args.quick and not args.no_large:
+        try:
+            lx, ly, ln = 4096, 4096, 60
+            # smooth 16-bit content made on the GPU (a few low-frequency sines + 4 bits of noise per frame; the
+            # host's plasma generator takes 4 s per frame of this size): 5 distinct frames, the first is the delta frame
+            gy, gx = torch.meshgrid(torch.arange(ly, device=dev, dtype=torch.float32), torch.arange(lx, device=dev, dtype=torch.float32), indexing="ij")
+            gen = torch.Generator(device=dev); gen.manual_seed(11)
+            l5 = []
+            for k in range(5):
+                v = 30000 + 9000 * torch.sin(gx / (310.0 + 7 * k) + 0.3 * k) + 7000 * torch.sin(gy / (270.0 - 5 * k) + 0.2 * k) + 5000 * torch.sin((gx + gy) / (530.0 + 11 * k))
+                v = v + torch.randint(0, 16, (ly, lx), device=dev, generator=gen)
+                l5.append(v.clamp(0, 65535).to(torch.int32).to(torch.uint16))
+            del gy, gx, v
+            lbase0 = l5[0].cpu().numpy()
+            lfr = torch.stack([l5[1 + (k % 4)] for k in range(ln)]).contiguous().reshape(-1)
+            del l5
+            lres, lout = {}, None
+            for tag, env in (("groups_of_64_frames_tile_by_tile", {}), ("frame_by_frame", {"FPV_TILE_FGROUP": "0"})):
+                os.environ.update(env)
+                pl = pkg.Predictor(lx, ly, 0, False, max_batch=ln, slots=0, device=local_rank)
+                for k in env:
+                    os.environ.pop(k)
+                pl.set_delta_raw(lbase0)
+                lout = lout or pl.alloc_outputs(ln)
+                for _ in range(3):
+                    pl.predict(lfr, out=lout)
+                torch.cuda.synchronize()
+                lres[tag] = min(pl.time_predict(lfr, lout, 10) / 10 for _ in range(3))
+                lnames = pl.forward_kernel_names()
+                lflags = lout[3].cpu().numpy()
+                pl.close()
+            lms = lres["groups_of_64_frames_tile_by_tile"]
+            lbytes = ln * lx * ly * 4.0625
+            large = {"workload": "4096x4096 16-bit smooth synthetic frames (BASELINE config 3's frame size), 60 frames resident in HBM, one delta frame",
+                     "flags_histogram": {str(k): int(v) for k, v in zip(*np.unique(lflags, return_counts=True))},
+                     "ms_per_step": round(lms, 4), "frames_per_s": round(ln / lms * 1e3, 1),
+                     "algorithmic_GBps_all_kernels": round(lbytes / lms / 1e6, 1), "frac_all_kernels": round(lbytes / lms / 1e6 / HBM_PEAK_GBPS, 4),
+                     "ms_per_step_frame_by_frame": round(lres["frame_by_frame"], 4), "kernels": lnames,
+                     "note": "default order for frames whose delta planes pass 8 MB: groups of 64 frames walked tile by tile, so that a tile's "
+                             "delta bytes are fetched once per group; frame by frame (FPV_TILE_FGROUP=0, the order of smaller frames) every "
+                             "frame re-reads the 33.5 MB of delta planes"}
+            del lfr, lout
+            torch.cuda.empty_cache()
+        except Exception as e:   # reported, never fatal for the headline
+            large = {"error": f"{type(e).__name__}: {e}"}
+
     if rank == 0:
         fps = world * n * args.steps / elapsed
         cm = np.array(chunk_ms)
@@ -592,6 +643,8 @@ def main():
             res["inverse"] = inv
         if adv is not None:
             res["adversarial"] = adv
+        if large is not None:
+            res["large_frames"] = large
         if pmc is not None:
             if "error" in pmc:
                 res["roofline"]["traffic_error"] = pmc["error"]

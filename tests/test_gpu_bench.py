@@ -50,6 +50,10 @@ def test_bench_line_contract():
         assert 0.98 * rf["algorithmic_bytes_per_launch"] <= rf["traffic"] <= 1.25 * rf["algorithmic_bytes_per_launch"]
         adv = d["adversarial"]
         assert "traffic_error" not in adv and 1.0 < adv["traffic_over_algorithmic"] < 1.8, adv
+    # BASELINE config 3's frame size: the order large frames take (groups of frames tile by tile) beats the memory order
+    lf = d["large_frames"]
+    assert "error" not in lf, lf
+    assert lf["flags_histogram"] == {"3": 60} and lf["ms_per_step"] < 0.95 * lf["ms_per_step_frame_by_frame"], lf
     mv = d["value_moving_window"]
     assert mv["frames_redone_per_step"] > 0 and 0.5 * d["value"] < mv["frames_per_s"] <= 1.05 * d["value"], mv
     # `value` comes from the first allocation; the survey is reported, never selected

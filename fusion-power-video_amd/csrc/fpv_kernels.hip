@@ -2987,7 +2987,9 @@ static hipError_t predict_impl(const Geom& g, const uint16_t* d_frames,
     if (g.tile_tiles > 64 || g.tile_decide_big) k_tile_decide<SWAP, true><<<nframes, 1024, 0, s>>>(L);   // many records per frame (large frames)
     else k_tile_decide<SWAP, false><<<nframes, 256, 0, s>>>(L);
     if (ev) hipEventRecord(ev[2], s);
-    const uint32_t rgrid = std::min<uint32_t>(nframes * g.tile_tiles, device_cus() * std::max(1u, 2048u / T));
+    // as many workgroups as are resident at once (two of 512 threads per CU at this kernel's registers): each takes its
+    // share of the frames' previews in one turn, then its share of the redo list
+    const uint32_t rgrid = std::min<uint32_t>(nframes * g.tile_tiles, device_cus() * std::max(1u, 1024u / T));
     if (lowp) k_tile_finish<SWAP, true><<<rgrid, T, lds, s>>>(L);
     else k_tile_finish<SWAP, false><<<rgrid, T, lds, s>>>(L);
     if (ev) hipEventRecord(ev[3], s);

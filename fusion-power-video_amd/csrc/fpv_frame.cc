@@ -195,7 +195,8 @@ class PredictCombiner {
     } else {
       FrameFail("fpvhip_stage_in", fpvhip_last_error(ctx_));
       l.lock();
-      b->failed = bad_ = true;
+      b->failed = true;
+      bad_ = true;
       l.unlock();
     }
     l.lock();
@@ -219,7 +220,7 @@ class PredictCombiner {
       if (ok && fpvhip_predict_wait(ctx_, (uint32_t)b->slot, &b->high, &b->low, &b->preview, &b->flags))
         ok = FrameFail("fpvhip_predict_wait", fpvhip_last_error(ctx_));
       l.lock();
-      if (!ok) b->failed = bad_ = true;
+      if (!ok) { b->failed = true; bad_ = true; }
       b->done = true;
       inflight_ = false;
       cv_.notify_all();
@@ -264,7 +265,7 @@ class PredictCombiner {
   std::mutex m_;
   std::condition_variable cv_;
   fpvhip_ctx* ctx_ = nullptr;
-  bool bad_ = false;  // the context saw a failure: destroyed, not cached, when the combiner goes
+  std::atomic<bool> bad_{false};  // the context saw a failure: destroyed, not cached, when the combiner goes (written under mu_, read by Get under the registry's lock)
   size_t npix_, npv_;
   uint32_t max_batch_;
   std::atomic<int64_t> last_used_ms_{0};

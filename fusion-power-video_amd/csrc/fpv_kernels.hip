@@ -2976,8 +2976,8 @@ static hipError_t predict_impl(const Geom& g, const uint16_t* d_frames,
     const bool lowp = g.shift != 8;
     const uint32_t T = g.tile_threads, lds = g.tile_lds;
     if (ev) hipEventRecord(ev[0], s);
-#if FPV_TILE_PAIR || FPV_TILE_XGROUP > 1  // experiments: a flat grid
-    const dim3 tgrid((FPV_TILE_PAIR ? (nframes + 1) / 2 : nframes) * g.tile_tiles);
+#if FPV_TILE_XGROUP > 1  // experiment: a flat grid
+    const dim3 tgrid(nframes * g.tile_tiles);
 #else
     const dim3 tgrid(g.tile_tiles << a.lfgroup, (nframes + (1u << a.lfgroup) - 1u) >> a.lfgroup);  // x fastest; nframes <= 65535 (create_impl)
 #endif

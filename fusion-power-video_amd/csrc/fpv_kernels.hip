@@ -2298,8 +2298,13 @@ __global__ __launch_bounds__(192) void k_inverse_trio(
           for (int k = k0; k < k1; k++) {
             const uint32_t ic = min(head + t * S + (k * 64 + lane) * 4, last4);
             dma4(lsrc + ic, base + k * 256);
+#ifdef FPV_EXP_DELTA_WINDOW  // timing experiment only (wrong pixels): the delta planes' bytes from a 4 KB window that stays in the L1
+            dma4(dhsrc + (ic & 4095u), base + S + k * 256);
+            dma4(dlsrc + (ic & 4095u), base + 2 * S + k * 256);
+#else
             dma4(dhsrc + ic, base + S + k * 256);
             dma4(dlsrc + ic, base + 2 * S + k * 256);
+#endif
           }
         } else {
           all = false;

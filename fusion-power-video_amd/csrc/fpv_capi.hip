@@ -787,8 +787,8 @@ int fpvhip_inverse_pass_stats(fpvhip_ctx* c, uint32_t* out, int reset) {
   {
     uint32_t w[16];
     HIPOK(c, hipMemcpy(w, c->d_inv_diag, 64, hipMemcpyDeviceToHost));
-    fprintf(stderr, "EXP_WAITS chain: at barriers %u of %u; i/o wave 1: at barriers %u of %u (x16 clocks, summed over frames)\n",
-            w[4], w[5], w[8], w[7]);
+    fprintf(stderr, "EXP_WAITS chain: at barriers %u of %u; i/o wave 1: at barriers %u, waiting for its planes %u, for residuals + stores in front of the barrier %u, of %u (x16 clocks, summed over frames)\n",
+            w[4], w[5], w[8], w[9], w[10], w[7]);
   }
 #endif
   if (reset) HIPOK(c, hipMemset(c->d_inv_diag, 0, 64));

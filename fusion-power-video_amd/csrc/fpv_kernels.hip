@@ -2023,13 +2023,29 @@ __device__ __forceinline__ void dma4(const uint8_t* src, uint8_t* dst_wave_unifo
                                    reinterpret_cast<uint32_t*>(dst_wave_uniform), 4, 0, 0);
 }
 
+// 64 lanes x 16 bytes (1 KiB per instruction, gfx950's global_load_lds_dwordx4) into LDS at dst + 16 * lane.
+__device__ __forceinline__ void dma16(const uint8_t* src, uint8_t* dst_wave_uniform) {
+  __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t*>(src),
+                                   reinterpret_cast<uint32_t*>(dst_wave_uniform), 16, 0, 0);
+}
+
 // SIMDs with a chain wave of k_inverse_trio on them, one word per CU (index: XCC, SE, SH, CU of
 // HW_ID), bits 0..3.  Device-wide on purpose: the claim is about the physical SIMD, whichever
 // context or stream the other frame belongs to.
 constexpr uint32_t kChainSimdWords = 4096;
 __device__ uint32_t g_chain_simd_mask[kChainSimdWords];
 
-template <int K4, int M>
+// IP (round 5, "in place"): the residual bytes are loaded straight into the RING, at the place where the chain wave will
+// put the pixel it makes of them, TWO blocks ahead of the chain wave instead of one; the low plane has two buffers and is
+// loaded a whole phase ahead.  Measured with clock stamps (tools/exp/inv_waits.py, 1000 frames): the chain wave stood at the
+// barrier for 12 % of its life and an i/o wave waited 9 % for its plane bytes and 10 % for residuals and store
+// acknowledgements in front of the barrier -- each side late for the other in turn, one block of slack being less than
+// a loaded HBM round trip.  With the residuals two blocks ahead nothing is waited for in front of the barrier at all, and
+// what the i/o wave waits for at the top of a phase was issued a whole phase earlier (the delta planes' bytes, L2 hits, half
+// a phase).  The ring is a whole number of supersteps (not a power of two: the slot of a superstep is a counter), and
+// supersteps start at ring offsets that are multiples of S, so a DMA piece (256 bytes) never wraps.  Needs xs % K == 0
+// (a lane's north bytes then never straddle the ring's end).
+template <int K4, int M, bool IP = false>
 __global__ __launch_bounds__(192) void k_inverse_trio(
     const uint8_t* __restrict__ high, const uint8_t* __restrict__ low,
     const uint8_t* __restrict__ dhigh, const uint8_t* __restrict__ dlow,
@@ -2038,9 +2054,11 @@ __global__ __launch_bounds__(192) void k_inverse_trio(
   constexpr int K = 4 * K4;
   constexpr uint32_t S = 64u * K;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  uint8_t* ring = smem;                 // reconstructed high bytes: pixel i at rix(i) = (i - 4) & m
-  uint8_t* rbuf = smem + ring_bytes;    // residual bytes of superstep t at rbuf + (t & (2 M - 1)) * S
-  uint8_t* lbuf = rbuf + 2 * M * S;     // low / delta-high / delta-low bytes of the q-th superstep of a block at lbuf + (q * 3 + plane) * S
+  uint8_t* ring = smem;                 // reconstructed high bytes: pixel i at rix(i) = (i - 4) & m  (IP: (i - head) mod ring_bytes)
+  uint8_t* rbuf = smem + ring_bytes;    // residual bytes of superstep t at rbuf + (t & (2 M - 1)) * S  (IP: none, they are in the ring)
+  // low / delta-high / delta-low bytes of the q-th superstep of a block at lbuf + (q * 3 + plane) * S
+  // (IP: at lbuf + q * 4 S: low of even blocks, low of odd blocks, delta high, delta low)
+  uint8_t* lbuf = IP ? rbuf : rbuf + 2 * M * S;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   uint32_t role = wave;  // 0 chain, 1 and 2 i/o; frames with a chain reassign it below (the SIMD claim)
   const uint32_t frame = blockIdx.x, lane = threadIdx.x & 63;
@@ -2055,7 +2073,11 @@ __global__ __launch_bounds__(192) void k_inverse_trio(
   const uint32_t f = flags[frame];
   const bool use_delta = (f & 1) && dhigh, use_cg = f & 2, no_low = (f & 4) || !lp;
   const uint32_t xs = g.xs, npix = g.npix, m = ring_bytes - 1;
-  auto rix = [&](uint32_t i) { return (i - 4u) & m; };  // ring offset of pixel i (see the chain wave's 128-bit accesses)
+  const uint32_t head = min(xs + 4, npix);
+  const uint32_t nslots = ring_bytes / S;  // IP: the ring is nslots supersteps long; superstep t lies at (t mod nslots) * S
+  // ring offset of pixel i (see the chain wave's 128-bit accesses).  IP: the general form, used outside the loops only
+  // (pixels in front of the first superstep lie at the ring's end: ring_bytes >= head)
+  auto rix = [&](uint32_t i) { return IP ? (i + ring_bytes - head) % ring_bytes : (i - 4u) & m; };
 
   // delta^-1 + recombine (cc:335-344) of 4 pixels; planes that do not exist come as zeros
   auto emit4 = [&](uint32_t i, uint32_t h4, uint32_t l4, uint32_t dh4, uint32_t dl4) {
@@ -2126,7 +2148,6 @@ __global__ __launch_bounds__(192) void k_inverse_trio(
     return;
   }
 
-  const uint32_t head = min(xs + 4, npix);
   const uint32_t nsteps = (npix - head + S - 1) / S;
   const uint32_t nblocks = (nsteps + M - 1) / M;  // the waves meet once per block of M supersteps
 
@@ -2138,7 +2159,7 @@ __global__ __launch_bounds__(192) void k_inverse_trio(
   // 1.62 M and every other frame stayed under 1.74 M -- a seventh of the batch time for one pair.
   // Per CU a word in device memory holds the SIMDs taken; a workgroup claims a free one among
   // those its waves are on (returning atomics, once per frame) and gives it back at the end.
-  uint32_t* ctl = reinterpret_cast<uint32_t*>(rbuf + 5 * M * S);  // 8 words behind the plane slots
+  uint32_t* ctl = reinterpret_cast<uint32_t*>(IP ? lbuf + 4 * M * S : rbuf + 5 * M * S);  // 8 words behind the plane slots
   uint32_t claimed_simd = 4, cu_index = 0;
   {
     uint32_t hw, xcc;
@@ -2172,12 +2193,18 @@ __global__ __launch_bounds__(192) void k_inverse_trio(
 #endif
   uint32_t w_prev = 0, npass = 0, maxpass = 0;  // chain wave
 #ifdef FPV_EXP_WAITS  // experiment: where the waves of a frame wait (shader clocks, summed over the frame)
-  uint64_t exp_bar = 0, exp_t0 = clock64();
+  uint64_t exp_bar = 0, exp_t0 = clock64(), exp_top = 0, exp_pre = 0;  // at the barriers; i/o: in the wait for the planes (top of a phase), in the wait in front of the barrier
 #endif
 #ifndef FPV_NO_CHAIN_PRIO
   // The chain wave is the frame's critical path; on its SIMD it competes with i/o waves of
   // other frames.  Issue arbitration goes by priority first, then age (MI355X_MICROARCH.md).
-  if (role == 0) __builtin_amdgcn_s_setprio(3);
+#ifndef FPV_EXP_CHAIN_PRIO  // experiments (profiles/r05_inverse_ab.log): other priorities for the two roles
+#define FPV_EXP_CHAIN_PRIO 3
+#endif
+  if (role == 0) __builtin_amdgcn_s_setprio(FPV_EXP_CHAIN_PRIO);
+#endif
+#ifdef FPV_EXP_IO_PRIO
+  if (role != 0) __builtin_amdgcn_s_setprio(FPV_EXP_IO_PRIO);
 #endif
 
   // i/o wave 1 owns the k-groups [0, KA) of every superstep (64 lanes x 4 bytes each), i/o
@@ -2188,6 +2215,11 @@ __global__ __launch_bounds__(192) void k_inverse_trio(
 #pragma unroll
     for (int k = k0; k < k1; k++)
       dma4(hp + min(head + t * S + (k * 64 + lane) * 4, last4), rbuf + (t & (2 * M - 1)) * S + k * 256);
+  };
+  auto dma_r_ip = [&](uint32_t t, uint32_t slot, auto k0, auto k1) {  // IP: into the ring, superstep t's place
+#pragma unroll
+    for (int k = k0; k < k1; k++)
+      dma4(hp + min(head + t * S + (k * 64 + lane) * 4, last4), ring + slot * S + k * 256);
   };
   using IC0 = std::integral_constant<int, 0>;
   using ICA = std::integral_constant<int, KA>;
@@ -2216,7 +2248,11 @@ __global__ __launch_bounds__(192) void k_inverse_trio(
     w_prev = (uint32_t)ring[rix(head - 1)] << 8;  // wave-uniform: final x[s-1] << 8
   } else {  // residuals of block 0
     auto first = [&](auto k0, auto k1) {
-      for (uint32_t t = 0; t < (uint32_t)M && t < nsteps; t++) dma_r(t, k0, k1);
+      if (IP) {  // blocks 0 and 1 (2 M <= nslots: slot t)
+        for (uint32_t t = 0; t < 2u * M && t < nsteps; t++) dma_r_ip(t, t, k0, k1);
+      } else {
+        for (uint32_t t = 0; t < (uint32_t)M && t < nsteps; t++) dma_r(t, k0, k1);
+      }
     };
     if (role == 1) first(IC0{}, ICA{});
     else first(ICA{}, ICK{});
@@ -2240,7 +2276,13 @@ __global__ __launch_bounds__(192) void k_inverse_trio(
   auto io_phase = [&](uint32_t b, auto k0, auto k1) {
     constexpr int NK = decltype(k1)::value - decltype(k0)::value;
     if constexpr (NK > 0) {
+#ifdef FPV_EXP_WAITS
+      const uint64_t exp_a = clock64();
+#endif
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the planes of block b - 1 have landed
+#ifdef FPV_EXP_WAITS
+      exp_top += clock64() - exp_a;
+#endif
 #pragma unroll
       for (int q = 0; q < M; q++) {
         const uint32_t t = (b + 1) * M + q;
@@ -2314,8 +2356,117 @@ __global__ __launch_bounds__(192) void k_inverse_trio(
       // 4 * M * NK instead of 3 * M * NK operations: only the residual loads, the oldest, have to be
       // back --: +0.5 ... +0.9 % at 1000 frames.  The stores' acknowledgements are not what the i/o
       // waves wait for.)
+#ifdef FPV_EXP_WAITS
+      const uint64_t exp_c = clock64();
+#endif
       if (all) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * M * NK) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef FPV_EXP_WAITS
+      exp_pre += clock64() - exp_c;
+#endif
+    }
+  };
+  // IP: one phase of an i/o wave.  (1) the residuals of block b + 2 into the ring; (2) the low plane of block b into the low
+  // buffer of its parity (emitted a phase later); (3) a counted wait that leaves those two groups in flight: everything older
+  // is back -- the residuals of block b + 1 (the chain wave's next block), the low plane and the delta planes' bytes of block
+  // b - 1; (4) the output of block b - 1; (5) the delta planes' bytes of block b into the slots just read.  Nothing is waited
+  // for in front of the barrier.  The two i/o waves split the work by SUPERSTEP (wave 1 the even ones of a block, wave 2 the
+  // odd ones: a wave emits what it has loaded itself, so its own counted wait is all the ordering its plane bytes need), and a
+  // superstep's bytes come in pieces of 1 KiB (global_load_lds_dwordx4: a quarter of the DMA instructions, each of which costs
+  // the issuing wave a hundred clocks or more -- with dword pieces the i/o waves needed the whole phase just to issue theirs).
+  const uint32_t last16 = npix - 16;  // (npix >= 16: the kernel is not chosen for rows shorter than 256 pixels)
+  // S bytes of `plane` that belong to superstep t -> dst (wave-uniform).  Returns false when the superstep is the frame's last
+  // (dword pieces with clamped addresses then: a 16-byte piece could reach past the end of the plane)
+  auto dma_span = [&](const uint8_t* plane, uint32_t t, uint8_t* dst) -> bool {
+    constexpr int P16 = S / 1024, P4 = (S % 1024) / 256;
+    const uint32_t s0 = head + t * S;
+    if (s0 + S + 12 <= npix) {
+#pragma unroll
+      for (int p = 0; p < P16; p++) dma16(plane + s0 + p * 1024 + lane * 16, dst + p * 1024);
+#pragma unroll
+      for (int p = 0; p < P4; p++) dma4(plane + s0 + P16 * 1024 + p * 256 + lane * 4, dst + P16 * 1024 + p * 256);
+      return true;
+    }
+#pragma unroll
+    for (int k = 0; k < K4; k++) dma4(plane + min(s0 + (k * 64 + lane) * 4, last4), dst + k * 256);
+    return false;
+  };
+  uint32_t io_rslot = (2u * M) % nslots, io_eslot = 0;  // ring slots of the first supersteps of blocks b + 2 and b - 1 (counters, as the chain wave's)
+  auto slot_at = [&](uint32_t s0, int q) { const uint32_t v = s0 + q; return v >= nslots ? v - nslots : v; };
+  auto io_phase_ip = [&](uint32_t b, auto wp) {
+    constexpr int WP = decltype(wp)::value;          // this wave's supersteps of a block: q = WP, WP + 2, ..
+    constexpr int NQ = (M - WP + 1) / 2;
+    constexpr int NP = (int)(S / 1024 + (S % 1024) / 256);  // DMA pieces per superstep and plane
+    if constexpr (NQ > 0) {
+      bool all = true;
+      const uint32_t par = b & 1u;
+#pragma unroll
+      for (int q = WP; q < M; q += 2) {
+        const uint32_t t = (b + 2) * M + q;
+        if (t < nsteps) all = dma_span(hp, t, ring + slot_at(io_rslot, q) * S) && all;
+        else all = false;
+      }
+      const uint32_t eslot = io_eslot;
+      io_rslot = slot_at(io_rslot, M);
+      if (b >= 1) io_eslot = slot_at(io_eslot, M);
+#pragma unroll
+      for (int q = WP; q < M; q += 2) {
+        const uint32_t t = b * M + q;
+        if (t < nsteps) all = dma_span(lsrc, t, lbuf + q * 4 * S + par * S) && all;
+        else all = false;
+      }
+#ifdef FPV_EXP_WAITS
+      const uint64_t exp_a = clock64();
+#endif
+      if (all) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NQ * NP) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef FPV_EXP_WAITS
+      exp_top += clock64() - exp_a;
+#endif
+#pragma unroll
+      for (int q = WP; q < M; q += 2) {
+        const uint32_t t = (b - 1) * M + q;
+        if (b >= 1 && t < nsteps) {
+          const uint32_t s0 = head + t * S;
+          const uint32_t rbase = ring_lds + slot_at(eslot, q) * S;
+          const uint32_t base = lbuf_lds + q * 4 * S;
+          const bool full = s0 + S <= npix;  // every superstep but the last one
+#pragma unroll
+          for (int k0 = 0; k0 < K4; k0 += 2) {  // two k-groups (64 lanes x 4 bytes each) per statement
+            const int nk = k0 + 1 < K4 ? 2 : 1;
+            uint32_t h4[2], l4[2], dh4[2], dl4[2], ra[2], pa[2], la[2];
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+              const uint32_t o = ((k0 + (k < nk ? k : 0)) * 64 + lane) * 4;
+              ra[k] = rbase + o;
+              pa[k] = base + o;
+              la[k] = base + (par ^ 1u) * S + o;  // block b - 1's parity
+            }
+            // reads and their wait in ONE statement: no value exists outside it before it has landed
+            // (8 pixels per lane -- 64-bit reads, 16-byte stores -- measured no faster: profiles/r05_inverse_ab.log)
+#define FPV_RD4I(H, L, DH, DL, RA, LA, PA) \
+  "ds_read_b32 " H ", " RA "\n\tds_read_b32 " L ", " LA "\n\tds_read_b32 " DH ", " PA " offset:%c[s2]\n\tds_read_b32 " DL ", " PA " offset:%c[s3]\n\t"
+            static_assert(3 * S < 65536, "plane offsets are DS immediates");
+            asm volatile(FPV_RD4I("%0", "%1", "%2", "%3", "%8", "%9", "%10") FPV_RD4I("%4", "%5", "%6", "%7", "%11", "%12", "%13") "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(h4[0]), "=&v"(l4[0]), "=&v"(dh4[0]), "=&v"(dl4[0]), "=&v"(h4[1]), "=&v"(l4[1]), "=&v"(dh4[1]), "=&v"(dl4[1])
+                         : "v"(ra[0]), "v"(la[0]), "v"(pa[0]), "v"(ra[1]), "v"(la[1]), "v"(pa[1]), [s2] "n"(2 * S), [s3] "n"(3 * S) : "memory");
+#undef FPV_RD4I
+#pragma unroll
+            for (int k = 0; k < nk; k++) {
+              const uint32_t px = s0 + ((k0 + k) * 64 + lane) * 4;
+              if (full || px < npix) emit4(px, h4[k], l4[k] & lmask, dh4[k] & dmask, dl4[k] & dmask);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int q = WP; q < M; q += 2) {  // (the reads above have returned: the delta slots may be refilled)
+        const uint32_t t = b * M + q;
+        if (t < nsteps) {
+          dma_span(dhsrc, t, lbuf + q * 4 * S + 2 * S);
+          dma_span(dlsrc, t, lbuf + q * 4 * S + 3 * S);
+        }
+      }
     }
   };
   // Each role runs its own loop over the blocks; every wave passes the same nblocks + 1 barriers.
@@ -2329,6 +2480,7 @@ __global__ __launch_bounds__(192) void k_inverse_trio(
 #endif
   };
   if (role == 0) {
+    uint32_t cslot = 0;  // IP: the ring slot of superstep t
     for (uint32_t b = 0; b <= nblocks; b++) {
 #pragma unroll 1
       for (uint32_t t = b * M; t < (b + 1) * M && t < nsteps; t++) {
@@ -2340,10 +2492,32 @@ __global__ __launch_bounds__(192) void k_inverse_trio(
         uint32_t N[K], D[K], R[K], X[K];
 #endif
         uint32_t guess;
+        // IP: ring offsets of this lane's segment (os), of the bytes above it (on: xs % K == 0, so they do not straddle the
+        // ring's end) and of the dword in front of those (onb)
+        uint32_t os = 0, on = 0, onb = 0;
+        if (IP) {
+          os = cslot * S + lane * K;
+          cslot = cslot + 1 == nslots ? 0 : cslot + 1;  // superstep t lies at slot t mod nslots (a counter: nslots is no power of two)
+          on = os >= xs ? os - xs : os + ring_bytes - xs;
+          onb = on >= 4 ? on - 4 : ring_bytes - 4;
+        }
         {
           const uint32_t nb = start - xs - 4;  // dword holding the north-west of the first pixel
           uint32_t nd[K4 + 1], rq[K4];
-          if constexpr (K4 == 4) {
+          if constexpr (IP) {
+            nd[0] = *reinterpret_cast<const uint32_t*>(ring + onb);
+            if constexpr (K4 == 4) {  // 16-byte accesses: os, xs and the ring's length are multiples of 16
+              const uint4 a = *reinterpret_cast<const uint4*>(ring + on);
+              nd[1] = a.x; nd[2] = a.y; nd[3] = a.z; nd[4] = a.w;
+              const uint4 r = *reinterpret_cast<const uint4*>(ring + os);
+              rq[0] = r.x; rq[1] = r.y; rq[2] = r.z; rq[3] = r.w;
+            } else {
+#pragma unroll
+              for (int q = 0; q < K4; q++) nd[q + 1] = *reinterpret_cast<const uint32_t*>(ring + on + 4 * q);
+#pragma unroll
+              for (int q = 0; q < K4; q++) rq[q] = *reinterpret_cast<const uint32_t*>(ring + os + 4 * q);
+            }
+          } else if constexpr (K4 == 4) {
             // 16 bytes per lane: dword accesses at a lane stride of 16 bytes are four-way bank conflicts
             // (odd K4: conflict-free), one 128-bit access per lane is not.  The ring is laid out so
             // that a lane's four north dwords, and (xs % 16 == 0) the four it writes, are aligned.
@@ -2465,7 +2639,14 @@ __global__ __launch_bounds__(192) void k_inverse_trio(
         for (int q = 0; q < K4; q++)
           packed[q] = __builtin_amdgcn_perm(X[4 * q + 1], X[4 * q], 0x0c0c0501u) |
                       __builtin_amdgcn_perm(X[4 * q + 3], X[4 * q + 2], 0x05010c0cu);
-        if (K4 == 4 && (xs & 15) == 0) {  // rix(start) = (xs + t * S + lane * 16) & m: 16-byte aligned
+        if constexpr (IP) {  // over the residuals they were made of
+          if constexpr (K4 == 4) {
+            *reinterpret_cast<uint4*>(ring + os) = make_uint4(packed[0], packed[1], packed[2], packed[K4 - 1]);
+          } else {
+#pragma unroll
+            for (int q = 0; q < K4; q++) *reinterpret_cast<uint32_t*>(ring + os + 4 * q) = packed[q];
+          }
+        } else if (K4 == 4 && (xs & 15) == 0) {  // rix(start) = (xs + t * S + lane * 16) & m: 16-byte aligned
           *reinterpret_cast<uint4*>(ring + rix(start)) = make_uint4(packed[0], packed[1], packed[2], packed[K4 - 1]);
         } else {
 #pragma unroll
@@ -2476,12 +2657,14 @@ __global__ __launch_bounds__(192) void k_inverse_trio(
     }
   } else if (role == 1) {
     for (uint32_t b = 0; b <= nblocks; b++) {
-      io_phase(b, IC0{}, ICA{});
+      if constexpr (IP) io_phase_ip(b, IC0{});
+      else io_phase(b, IC0{}, ICA{});
       sync();
     }
   } else {
     for (uint32_t b = 0; b <= nblocks; b++) {
-      io_phase(b, ICA{}, ICK{});
+      if constexpr (IP) io_phase_ip(b, std::integral_constant<int, 1>{});
+      else io_phase(b, ICA{}, ICK{});
       sync();
     }
   }
@@ -2490,7 +2673,10 @@ __global__ __launch_bounds__(192) void k_inverse_trio(
   if (pass_count && lane == 0) {
     const uint32_t tot = (uint32_t)((clock64() - exp_t0) >> 4);
     if (role == 0) { atomicAdd(&pass_count[4], (uint32_t)(exp_bar >> 4)); atomicAdd(&pass_count[5], tot); }
-    if (role == 1) { atomicAdd(&pass_count[8], (uint32_t)(exp_bar >> 4)); atomicAdd(&pass_count[7], tot); }
+    if (role == 1) {
+      atomicAdd(&pass_count[8], (uint32_t)(exp_bar >> 4)); atomicAdd(&pass_count[7], tot);
+      atomicAdd(&pass_count[9], (uint32_t)(exp_top >> 4)); atomicAdd(&pass_count[10], (uint32_t)(exp_pre >> 4));
+    }
   }
 #endif
   if (pass_count && role == 0 && lane == 0) {  // diagnostics: supersteps and passes (bench / tests)
@@ -3085,32 +3271,41 @@ static uint32_t trio_block_max() {  // FPV_TRIO_BLOCK caps it; read per launch: 
   const int v = e ? atoi(e) : 4;
   return v >= 4 ? 4u : v >= 2 ? 2u : 1u;
 }
-static uint32_t trio_ring(const Geom& g, uint32_t k4, uint32_t mblk) {
+// ip (k_inverse_trio<K4, M, true>): residuals in place, two blocks ahead.  The ring is a whole number of supersteps: the
+// block being emitted -- or, where a row is longer than a block, the supersteps that hold the row above the current block --,
+// the current block and two blocks of residuals ahead of it.
+static bool trio_ip_ok(const Geom& g, uint32_t k4) {  // a lane's north bytes must not straddle the ring's end
+  const char* e = getenv("FPV_TRIO_INPLACE");  // read per launch: A/B runs and tests switch inside one process
+  return !(e && atoi(e) == 0) && k4 && g.xs % (4 * k4) == 0;
+}
+static uint32_t trio_ring(const Geom& g, uint32_t k4, uint32_t mblk, bool ip = false) {
   const uint32_t S = 256 * k4;
+  if (ip) return (3 * mblk + std::max(mblk, (g.xs + 16 + S - 1) / S)) * S;
   uint32_t r = 1;
   while (r < 2 * mblk * S + g.xs + 16) r <<= 1;
   return r;
 }
-static size_t trio_lds(const Geom& g, uint32_t k4, uint32_t mblk) {  // ring, 2 M residual + 3 M plane slots, control words
-  return trio_ring(g, k4, mblk) + 5 * mblk * 256 * k4 + 64;
+static size_t trio_lds(const Geom& g, uint32_t k4, uint32_t mblk, bool ip = false) {  // ring, 2 M residual + 3 M plane slots (ip: 4 M plane slots), control words
+  return trio_ring(g, k4, mblk, ip) + (ip ? 4 : 5) * mblk * 256 * k4 + 64;
 }
 
 // Frames whose three-wave workgroups (k_inverse_trio<k4, mblk>) are all resident at the same
 // time on the current device: the runtime's occupancy answer for the instantiation times the CUs.
-static uint32_t trio_capacity(const Geom& g, uint32_t k4, uint32_t mblk) {
+static uint32_t trio_capacity(const Geom& g, uint32_t k4, uint32_t mblk, bool ip = false) {
   // The answer depends on the LDS bytes of the launch, i.e. on the frame width (the ring), not on
   // (k4, mblk) alone: a second context with another width must not reuse the first one's figure.
   struct Slot { uint32_t lds, cap; };
   static std::mutex m;
-  static Slot capm[64][kSpecMaxK4 + 1][5][4] = {};  // a few widths per instantiation; beyond that the oldest entry is replaced
+  static Slot capm[64][2][kSpecMaxK4 + 1][5][4] = {};  // a few widths per instantiation; beyond that the oldest entry is replaced
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) dev = 0;
   dev &= 63;
   if (k4 == 0 || k4 > kSpecMaxK4 || (mblk != 1 && mblk != 2 && mblk != 4)) return 0;
-  const size_t lds = trio_lds(g, k4, mblk);
+  if (ip && !trio_ip_ok(g, k4)) return 0;
+  const size_t lds = trio_lds(g, k4, mblk, ip);
   if (lds > 64 * 1024) return 0;
   std::lock_guard<std::mutex> l(m);
-  Slot* slots = capm[dev][k4][mblk];
+  Slot* slots = capm[dev][ip ? 1 : 0][k4][mblk];
   uint32_t* cap_slot = nullptr;
   for (int i = 0; i < 4 && !cap_slot; i++)
     if (slots[i].cap && slots[i].lds == (uint32_t)lds) cap_slot = &slots[i].cap;
@@ -3127,7 +3322,8 @@ static uint32_t trio_capacity(const Geom& g, uint32_t k4, uint32_t mblk) {
   if (!*cap_slot) {
     int blocks = 0;
     hipError_t e = hipErrorInvalidValue;
-#define FPV_OCC(K4, MB) if (k4 == K4 && mblk == MB) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_inverse_trio<K4, MB>, 192, lds);
+#define FPV_OCC(K4, MB) if (k4 == K4 && mblk == MB) e = ip ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_inverse_trio<K4, MB, true>, 192, lds) \
+                                                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_inverse_trio<K4, MB, false>, 192, lds);
 #define FPV_OCC3(K4) FPV_OCC(K4, 1) FPV_OCC(K4, 2) FPV_OCC(K4, 4)
     FPV_OCC3(1) FPV_OCC3(2) FPV_OCC3(3) FPV_OCC3(4) FPV_OCC3(5) FPV_OCC3(6)
 #undef FPV_OCC3
@@ -3150,10 +3346,11 @@ static uint32_t trio_capacity(const Geom& g, uint32_t k4, uint32_t mblk) {
 //   blocks of 2 at k4 - 1 (fewer registers)               5 per CU:                           1280 frames
 // (1000 frames: 0.787 ms with blocks of 4 at k4 - 1, 0.803 with blocks of 2 at k4, same run)
 // and one wave per frame beyond (a second round of workgroups would run nearly alone).
-static int inverse_mode(const Geom& g, uint32_t nframes, uint32_t* k4, uint32_t* mblk) {
+static int inverse_mode(const Geom& g, uint32_t nframes, uint32_t* k4, uint32_t* mblk, bool* ip) {
   int mode = -1;  // the environment is read per launch: tests switch kernels inside one process
   *k4 = g.spec_k4;
   *mblk = 1;
+  *ip = false;
   if (getenv("FPV_INVERSE_SLOW")) {
     mode = 2;
   } else if (const char* e = getenv("FPV_INVERSE")) {
@@ -3163,12 +3360,18 @@ static int inverse_mode(const Geom& g, uint32_t nframes, uint32_t* k4, uint32_t*
     const bool forced = mode == 3;
     const uint32_t mmax = trio_block_max();
     mode = 0;
+    // (per block length and segment length the in-place form first -- residuals two blocks ahead, round 5 -- where the width
+    // allows it and its LDS admits the batch; FPV_TRIO_INPLACE=0: never)
     for (uint32_t mb = mmax; mb >= 1 && mode == 0; mb >>= 1)
-      for (uint32_t kk = g.spec_k4; kk + 1 >= g.spec_k4 && kk >= 1 && mode == 0; kk--)
-        if (nframes <= trio_capacity(g, kk, mb)) { mode = 3; *k4 = kk; *mblk = mb; }
+      for (uint32_t kk = g.spec_k4; kk + 1 >= g.spec_k4 && kk >= 1 && mode == 0; kk--) {
+        if (nframes <= trio_capacity(g, kk, mb, true)) { mode = 3; *k4 = kk; *mblk = mb; *ip = true; }
+        else if (nframes <= trio_capacity(g, kk, mb)) { mode = 3; *k4 = kk; *mblk = mb; }
+      }
     if (mode == 0 && forced && g.spec_k4) {  // FPV_INVERSE=trio beyond the capacity: the longest block that fits
-      for (uint32_t mb = mmax; mb >= 1 && mode == 0; mb >>= 1)
-        if (trio_capacity(g, g.spec_k4, mb)) { mode = 3; *mblk = mb; }
+      for (uint32_t mb = mmax; mb >= 1 && mode == 0; mb >>= 1) {
+        if (trio_capacity(g, g.spec_k4, mb, true)) { mode = 3; *mblk = mb; *ip = true; }
+        else if (trio_capacity(g, g.spec_k4, mb)) { mode = 3; *mblk = mb; }
+      }
     }
   }
   return mode;
@@ -3183,7 +3386,8 @@ hipError_t set_chain_simd_mask(uint32_t value) {
 
 const char* inverse_kernel_name(const Geom& g, uint32_t nframes) {
   uint32_t k4, mblk;
-  const int mode = inverse_mode(g, nframes, &k4, &mblk);
+  bool ip;
+  const int mode = inverse_mode(g, nframes, &k4, &mblk, &ip);
   const bool aligned = (g.xs & 3) == 0 && (g.npix & 3) == 0;
   if (mode == 3 && g.spec_k4) return "k_inverse_trio";
   if (mode == 0 && g.spec_k4) return "k_inverse_spec";
@@ -3205,7 +3409,8 @@ hipError_t launch_inverse(const Geom& g, const uint8_t* d_high,
   // alone, and one wave per frame (more frames resident, less synchronisation) wins:
   // 1100 frames 1.35 ms against 1.56, 2000 frames 1.65 against 2.28 (profiles/r02_inverse_ab.log).
   uint32_t k4, mblk;
-  const int mode = inverse_mode(g, nframes, &k4, &mblk);
+  bool ip;
+  const int mode = inverse_mode(g, nframes, &k4, &mblk, &ip);
   const bool aligned = (g.xs & 3) == 0 && (g.npix & 3) == 0;
   if (mode == 3 && g.spec_k4) {
 #ifdef FPV_EXP_PITCH
@@ -3217,9 +3422,14 @@ hipError_t launch_inverse(const Geom& g, const uint8_t* d_high,
 #define FPV_TRIO_GEOM g
 #endif
 #define FPV_LAUNCH_TRIO(K4, MB)                                                                       \
-  if (k4 == K4 && mblk == MB)                                                                         \
-    k_inverse_trio<K4, MB><<<nframes, 192, trio_lds(g, K4, MB), s>>>(                                 \
-        d_high, d_low, d_dhigh, d_dlow, d_flags, d_frames, FPV_TRIO_GEOM, trio_ring(g, K4, MB), d_diag);
+  if (k4 == K4 && mblk == MB) {                                                                       \
+    if (ip)                                                                                           \
+      k_inverse_trio<K4, MB, true><<<nframes, 192, trio_lds(g, K4, MB, true), s>>>(                   \
+          d_high, d_low, d_dhigh, d_dlow, d_flags, d_frames, FPV_TRIO_GEOM, trio_ring(g, K4, MB, true), d_diag); \
+    else                                                                                              \
+      k_inverse_trio<K4, MB, false><<<nframes, 192, trio_lds(g, K4, MB), s>>>(                        \
+          d_high, d_low, d_dhigh, d_dlow, d_flags, d_frames, FPV_TRIO_GEOM, trio_ring(g, K4, MB), d_diag); \
+  }
 #define FPV_LAUNCH_TRIO3(K4) FPV_LAUNCH_TRIO(K4, 1) FPV_LAUNCH_TRIO(K4, 2) FPV_LAUNCH_TRIO(K4, 4)
     if (k4 < 1 || k4 > kSpecMaxK4) return hipErrorInvalidValue;
     FPV_LAUNCH_TRIO3(1) FPV_LAUNCH_TRIO3(2) FPV_LAUNCH_TRIO3(3)

@@ -74,6 +74,9 @@ while time.time() - t0 < budget:
         fr[1:] = fr[0]          # frames equal to the delta frame
     delta = fr[0] if rng.integers(0, 5) else None
     os.environ["FPV_INVERSE"] = str(rng.choice(["spec", "trio", "auto", "fast"], p=[0.4, 0.4, 0.1, 0.1]))  # read per launch
+    # the three-wave kernel: blocks of 1 / 2 / 4 supersteps, residuals in the ring two blocks ahead (round 5) or in their own slots
+    os.environ["FPV_TRIO_BLOCK"] = str(rng.choice(["1", "2", "4"]))
+    os.environ["FPV_TRIO_INPLACE"] = str(rng.choice(["1", "0"], p=[0.7, 0.3]))
     # forward path (read when the context is created): the tile pass with a random tile height where the
     # width allows it (multiples of 64), now and then the streaming kernels instead
     for k in ("FPV_TILE_GROUPS", "FPV_FORWARD", "FPV_TILE8_GROUPS", "FPV_TILE8_ROWS", "FPV_TILE_FGROUP"):

@@ -182,14 +182,22 @@ def test_adversarial_flat_rows_cascade(fpv, oracle):
     p.close()
 
 
+@pytest.mark.parametrize("inplace", ["1", "0"])
 @pytest.mark.parametrize("block", ["1", "2", "4"])
-@pytest.mark.parametrize("xs,ys,n", [(1280, 44, 40), (1024, 28, 24), (1284, 20, 9), (512, 36, 130)])
-def test_three_wave_block_lengths(fpv, oracle, block, xs, ys, n):
+@pytest.mark.parametrize("xs,ys,n", [(1280, 44, 40), (1024, 28, 24), (1284, 20, 9), (512, 36, 130), (1920, 12, 9), (3072, 8, 5)])
+def test_three_wave_block_lengths(fpv, oracle, block, xs, ys, n, inplace):
     """The three-wave kernel meets once per block of M supersteps (1, 2 or 4; FPV_TRIO_BLOCK caps
     it): frames whose superstep count is no multiple of the block, residual and plane slots
     reused block after block, more frames than CUs (several workgroups per CU: every chain wave
     claims a SIMD of its own), flags of every kind.  (Under the one-wave kernel of this file's
-    fixture the knob changes nothing: the same cases are one more parity run.)"""
+    fixture the knob changes nothing: the same cases are one more parity run.)
+    Both forms of the kernel: residuals loaded into the ring two blocks ahead (round 5; the default
+    where the width is a multiple of the segment length: every width here but 1284) and, with
+    FPV_TRIO_INPLACE=0, into slots of their own one block ahead.  1920 and 3072 wide: rows longer
+    than a block of one or two supersteps (the ring then holds the row above instead of the block
+    being emitted), segments of 24 pixels."""
+    old_ip = os.environ.get("FPV_TRIO_INPLACE")
+    os.environ["FPV_TRIO_INPLACE"] = inplace
     rng = np.random.default_rng(xs + ys * 3 + n)
     high = rng.integers(0, 256, (n, ys, xs), dtype=np.uint8)
     high[::3] = (rng.integers(0, 40, (len(high[::3]), ys, xs)) == 0) * 7   # long identity runs too
@@ -205,6 +213,10 @@ def test_three_wave_block_lengths(fpv, oracle, block, xs, ys, n):
             os.environ.pop("FPV_TRIO_BLOCK", None)
         else:
             os.environ["FPV_TRIO_BLOCK"] = old
+        if old_ip is None:
+            os.environ.pop("FPV_TRIO_INPLACE", None)
+        else:
+            os.environ["FPV_TRIO_INPLACE"] = old_ip
 
 
 def test_chain_simd_claim_fallback_and_recovery(fpv, oracle):

@@ -2375,12 +2375,12 @@ __global__ __launch_bounds__(192) void k_inverse_trio(
   // superstep's bytes come in pieces of 1 KiB (global_load_lds_dwordx4: a quarter of the DMA instructions, each of which costs
   // the issuing wave a hundred clocks or more -- with dword pieces the i/o waves needed the whole phase just to issue theirs).
   const uint32_t last16 = npix - 16;  // (npix >= 16: the kernel is not chosen for rows shorter than 256 pixels)
-  // S bytes of `plane` that belong to superstep t -> dst (wave-uniform).  Returns false when the superstep is the frame's last
-  // (dword pieces with clamped addresses then: a 16-byte piece could reach past the end of the plane)
+  // S bytes of `plane` that belong to superstep t -> dst (wave-uniform).  Returns false when the superstep is the frame's last and
+  // short (dword pieces with clamped addresses then: a 16-byte piece could reach past the end of the plane)
   auto dma_span = [&](const uint8_t* plane, uint32_t t, uint8_t* dst) -> bool {
     constexpr int P16 = S / 1024, P4 = (S % 1024) / 256;
     const uint32_t s0 = head + t * S;
-    if (s0 + S + 12 <= npix) {
+    if (s0 + S <= npix) {
 #pragma unroll
       for (int p = 0; p < P16; p++) dma16(plane + s0 + p * 1024 + lane * 16, dst + p * 1024);
 #pragma unroll
@@ -3339,12 +3339,15 @@ static uint32_t trio_capacity(const Geom& g, uint32_t k4, uint32_t mblk, bool ip
 // length (dwords per lane and superstep) the speculative kernels run with, *mblk = supersteps
 // per barrier of the three-wave kernel.
 // Three waves per frame as long as EVERY frame's workgroup is resident at the same time.  In
-// order of preference (1280x800 on MI355X; profiles/r03_inverse_sizes.log, r03_inverse_ab.log):
-//   blocks of 4 supersteps at the geometry's own k4 = 5   41 KB of LDS, 3 workgroups per CU:   768 frames
+// order of preference (1280x800 on MI355X; profiles/r05_inverse_ab.log):
+//   in place (round 5), blocks of 2 supersteps at the geometry's own k4 = 5   20 KB of LDS, 4 workgroups per CU (registers): 1024 frames
+//   in place, blocks of 2 at k4 - 1 (fewer registers)                         5 per CU:                                      1280 frames
+// then, for widths the in-place form does not take (xs % (4 k4) != 0) or with FPV_TRIO_INPLACE=0, round 3's order
+// (profiles/r03_inverse_sizes.log, r03_inverse_ab.log):
+//   blocks of 4 supersteps at k4 = 5                      41 KB of LDS, 3 workgroups per CU:   768 frames
 //   blocks of 4 at k4 - 1 (shorter supersteps)            37 KB, 4 per CU:                    1024 frames
 //   blocks of 2 at k4                                     21 KB, 4 per CU (registers):        1024 frames
 //   blocks of 2 at k4 - 1 (fewer registers)               5 per CU:                           1280 frames
-// (1000 frames: 0.787 ms with blocks of 4 at k4 - 1, 0.803 with blocks of 2 at k4, same run)
 // and one wave per frame beyond (a second round of workgroups would run nearly alone).
 static int inverse_mode(const Geom& g, uint32_t nframes, uint32_t* k4, uint32_t* mblk, bool* ip) {
   int mode = -1;  // the environment is read per launch: tests switch kernels inside one process
@@ -3360,18 +3363,20 @@ static int inverse_mode(const Geom& g, uint32_t nframes, uint32_t* k4, uint32_t*
     const bool forced = mode == 3;
     const uint32_t mmax = trio_block_max();
     mode = 0;
-    // (per block length and segment length the in-place form first -- residuals two blocks ahead, round 5 -- where the width
-    // allows it and its LDS admits the batch; FPV_TRIO_INPLACE=0: never)
+    // The in-place form first (residuals two blocks ahead, round 5) where the width allows it and its LDS admits the
+    // batch (FPV_TRIO_INPLACE=0: never), in blocks of TWO supersteps unless FPV_TRIO_BLOCK says otherwise: with the
+    // residuals that far ahead the shorter block is 1-2 % faster at every batch size (profiles/r05_inverse_ab.log), and it
+    // leaves the geometry's own segment length within four workgroups per CU (1280 wide: k4 = 5 up to 1024 frames).
+    const uint32_t ipm = getenv("FPV_TRIO_BLOCK") ? mmax : std::min(mmax, 2u);
+    for (uint32_t kk = g.spec_k4; kk + 1 >= g.spec_k4 && kk >= 1 && mode == 0; kk--)
+      if (nframes <= trio_capacity(g, kk, ipm, true)) { mode = 3; *k4 = kk; *mblk = ipm; *ip = true; }
     for (uint32_t mb = mmax; mb >= 1 && mode == 0; mb >>= 1)
-      for (uint32_t kk = g.spec_k4; kk + 1 >= g.spec_k4 && kk >= 1 && mode == 0; kk--) {
-        if (nframes <= trio_capacity(g, kk, mb, true)) { mode = 3; *k4 = kk; *mblk = mb; *ip = true; }
-        else if (nframes <= trio_capacity(g, kk, mb)) { mode = 3; *k4 = kk; *mblk = mb; }
-      }
+      for (uint32_t kk = g.spec_k4; kk + 1 >= g.spec_k4 && kk >= 1 && mode == 0; kk--)
+        if (nframes <= trio_capacity(g, kk, mb)) { mode = 3; *k4 = kk; *mblk = mb; }
     if (mode == 0 && forced && g.spec_k4) {  // FPV_INVERSE=trio beyond the capacity: the longest block that fits
-      for (uint32_t mb = mmax; mb >= 1 && mode == 0; mb >>= 1) {
-        if (trio_capacity(g, g.spec_k4, mb, true)) { mode = 3; *mblk = mb; *ip = true; }
-        else if (trio_capacity(g, g.spec_k4, mb)) { mode = 3; *mblk = mb; }
-      }
+      if (trio_capacity(g, g.spec_k4, ipm, true)) { mode = 3; *mblk = ipm; *ip = true; }
+      for (uint32_t mb = mmax; mb >= 1 && mode == 0; mb >>= 1)
+        if (trio_capacity(g, g.spec_k4, mb)) { mode = 3; *mblk = mb; }
     }
   }
   return mode;

@@ -474,8 +474,10 @@ def main():
         inv_bytes = n * 4 * NPIX                                  # B_dec = 4 * P
         inv = {"kernel": pred.inverse_kernel_name(n), "frames_per_s": round(n / inv_ms * 1e3, 1),
                "ms_per_batch": round(inv_ms, 4), "timed_region_s": round(inv_ms * it / 1e3, 3),
-               "bound": "the serial chain of one wave per frame and its hand-offs with the frame's two i/o waves (chain alone 0.65-0.73 ms, "
-                        "memory side alone 0.72-0.74 ms for this batch: DESIGN.md section 4); the HBM figures are given for comparison",
+               "bound": "at this batch size HBM in the kernel's access shape (a thousand frames walked in step, 2 B/pixel stored: with the pixel "
+                        "stores compiled out the batch takes 0.64 ms, with one chain pass per superstep instead of 2.8 no less than before: "
+                        "profiles/r05_inverse_ab.log; the memory side alone 0.72-0.74 ms); below ~800 frames the serial chain of one wave "
+                        "per frame (smaller_batches: the time per batch hardly moves); DESIGN.md section 4",
                "achieved": round(inv_bytes / inv_ms / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                "frac": round(inv_bytes / inv_ms / 1e6 / HBM_PEAK_GBPS, 4),
                "algorithmic_bytes_per_launch": inv_bytes,

@@ -5,7 +5,7 @@
 # and a 1 GiB calibration copy.  Results: gpurun_out/pmc_<tag>/ (+ _noise: the adversarial workload)
 set -u
 cd "$(dirname "$0")/.."
-TAG=${1:-r04}
+TAG=${1:-r05}
 export TMPDIR=/tmp
 run() {  # dir name counters...
   local dir=$1 name=$2; shift 2

@@ -4,7 +4,7 @@
 # (separate runs, no tracing domain mixed in), then the plain default bench.  Output: gpurun_out/<tag>/
 set -u
 cd "$(dirname "$0")/.."
-TAG=${1:-r04}
+TAG=${1:-r05}
 export TMPDIR=/tmp
 mkdir -p gpurun_out/$TAG
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$TAG/trace -- python3 bench.py --steps 200 --warmup 5 --quick > gpurun_out/$TAG/bench_under_rocprof.log 2>&1

@@ -400,6 +400,16 @@ def main():
         gathered = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(gathered, mine)
         per_rank = [[round(float(v), 4) for v in g.cpu()] for g in gathered]
+        # The process group has carried everything it is there for.  It ends HERE, for every rank: what follows is rank 0's
+        # own work (secondary figures on its GPU, then the reference encoder on the host's cores), and ranks that sat in a
+        # collective meanwhile would spin on CPUs that `cpu_baseline` is about to time.
+        pg_world = dist.get_world_size()
+        dist.barrier()
+        dist.destroy_process_group()
+        dist = None
+        if rank != 0:
+            pred.close()
+            return
     # The same workload through a window that moves by one frame per step (a batch position then
     # sees a different frame every time, as in a real stream): the per-position flags prediction
     # cannot learn the batch by heart, the 16 frames per cycle that equal the delta frame (CG off)
@@ -682,7 +692,7 @@ def main():
             res["per_rank"] = {"ms_per_step": [r[0] for r in per_rank],
                                "kernel_ms": [dict(zip(names[:3], r[1:4])) for r in per_rank],
                                "process_group": {"backend": args.dist_backend + (" (RCCL)" if args.dist_backend == "nccl" else ""),
-                                                 "world_size": dist.get_world_size(),
+                                                 "world_size": pg_world,
                                                  "carries": "barriers, the max-over-ranks of the elapsed time and this gather; no frame data"}}
         if not args.no_cpu_baseline and not args.quick:   # rank 0, whatever the number of GPUs: the reference on this host's cores
             res["cpu_baseline"] = cpu_baseline(base, threads)
@@ -694,9 +704,6 @@ def main():
                                            f"(cpu quota {cpu_quota()}); the GPU stage is hidden behind it")
         print(json.dumps(res), flush=True)
     pred.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -2045,7 +2045,10 @@ __device__ uint32_t g_chain_simd_mask[kChainSimdWords];
 // a phase).  The ring is a whole number of supersteps (not a power of two: the slot of a superstep is a counter), and
 // supersteps start at ring offsets that are multiples of S, so a DMA piece (256 bytes) never wraps.  Needs xs % K == 0
 // (a lane's north bytes then never straddle the ring's end).
-template <int K4, int M, bool IP = false>
+// RES (round 5, with IP and an even M): the row is exactly one superstep long (xs == 256 K4: 1280 wide at K4 = 5, 1024 at 4, 1536
+// at 6).  The bytes above a lane's segment are then the pixels the SAME lane made one superstep earlier: they stay in registers
+// (two sets taking turns), the chain wave reads no north bytes from the ring and unpacks none.
+template <int K4, int M, bool IP = false, bool RES = false>
 __global__ __launch_bounds__(192) void k_inverse_trio(
     const uint8_t* __restrict__ high, const uint8_t* __restrict__ low,
     const uint8_t* __restrict__ dhigh, const uint8_t* __restrict__ dlow,
@@ -2481,15 +2484,16 @@ __global__ __launch_bounds__(192) void k_inverse_trio(
   };
   if (role == 0) {
     uint32_t cslot = 0;  // IP: the ring slot of superstep t
-    for (uint32_t b = 0; b <= nblocks; b++) {
-#pragma unroll 1
-      for (uint32_t t = b * M; t < (b + 1) * M && t < nsteps; t++) {
+    uint32_t res_in = 0;  // RES: the (verified) incoming pixel of this lane's segment in the superstep before = the pixel above-left of its next segment
+    // One superstep of the chain wave.  N: the bytes above the lane's segment as v << 8 operands -- loaded from the ring, or (RES,
+    // every superstep but the first) already there: what the superstep before left in its X; X: receives the segment's pixels.
+    auto chain_step = [&](uint32_t t, uint32_t (&N)[K], uint32_t (&X)[K], bool north_in_regs) {
         const uint32_t s0 = head + t * S, start = s0 + lane * K;
         const bool active = start < npix;
 #if FPV_INV_LEAN
-        uint32_t N[K], D[K], X[K], RL[K4], RH[K4];  // residuals stay packed: see inv_px4w
+        uint32_t D[K], RL[K4], RH[K4];  // residuals stay packed: see inv_px4w
 #else
-        uint32_t N[K], D[K], R[K], X[K];
+        uint32_t D[K], R[K];
 #endif
         uint32_t guess;
         // IP: ring offsets of this lane's segment (os), of the bytes above it (on: xs % K == 0, so they do not straddle the
@@ -2501,7 +2505,33 @@ __global__ __launch_bounds__(192) void k_inverse_trio(
           on = os >= xs ? os - xs : os + ring_bytes - xs;
           onb = on >= 4 ? on - 4 : ring_bytes - 4;
         }
-        {
+        if (RES && north_in_regs) {
+          // The row is one superstep long: the bytes above this lane's segment are the pixels the same lane made a superstep ago
+          // (N holds them as it stands), the one above-left of its first pixel is that superstep's verified input.  Only the
+          // residuals come from LDS.
+          uint32_t rq[K4];
+          if constexpr (K4 == 4) {
+            const uint4 r = *reinterpret_cast<const uint4*>(ring + os);
+            rq[0] = r.x; rq[1] = r.y; rq[2] = r.z; rq[3] = r.w;
+          } else {
+#pragma unroll
+            for (int q = 0; q < K4; q++) rq[q] = *reinterpret_cast<const uint32_t*>(ring + os + 4 * q);
+          }
+          guess = res_in;
+          D[0] = N[0] - res_in;
+#pragma unroll
+          for (int k = 1; k < K; k++) D[k] = N[k] - N[k - 1];
+#pragma unroll
+          for (int q = 0; q < K4; q++) {
+#if FPV_INV_LEAN
+            RL[q] = r_lo(rq[q]);
+            RH[q] = r_hi(rq[q]);
+#else
+#pragma unroll
+            for (int b = 0; b < 4; b++) R[4 * q + b] = __builtin_amdgcn_perm(0, rq[q], 0x0c0c000cu | ((uint32_t)b << 8));
+#endif
+          }
+        } else {
           const uint32_t nb = start - xs - 4;  // dword holding the north-west of the first pixel
           uint32_t nd[K4 + 1], rq[K4];
           if constexpr (IP) {
@@ -2652,8 +2682,29 @@ __global__ __launch_bounds__(192) void k_inverse_trio(
 #pragma unroll
           for (int q = 0; q < K4; q++) *reinterpret_cast<uint32_t*>(ring + rix(start + 4 * q)) = packed[q];
         }
+        res_in = in;
+    };
+    if constexpr (RES) {
+      // Two register sets taking turns (M is even: even supersteps read P and write Q, odd ones the other way round): the
+      // pixels of one superstep ARE the north operands of the next, without a copy.
+      uint32_t P[K], Q[K];
+      for (uint32_t b = 0; b <= nblocks; b++) {
+#pragma unroll 1
+        for (uint32_t t = b * M; t < (b + 1) * M && t < nsteps; t += 2) {
+          chain_step(t, P, Q, t > 0);
+          if (t + 1 < nsteps) chain_step(t + 1, Q, P, true);
+        }
+        sync();
       }
-      sync();
+    } else {
+      for (uint32_t b = 0; b <= nblocks; b++) {
+#pragma unroll 1
+        for (uint32_t t = b * M; t < (b + 1) * M && t < nsteps; t++) {
+          uint32_t N[K], X[K];
+          chain_step(t, N, X, false);
+        }
+        sync();
+      }
     }
   } else if (role == 1) {
     for (uint32_t b = 0; b <= nblocks; b++) {
@@ -3278,6 +3329,27 @@ static bool trio_ip_ok(const Geom& g, uint32_t k4) {  // a lane's north bytes mu
   const char* e = getenv("FPV_TRIO_INPLACE");  // read per launch: A/B runs and tests switch inside one process
   return !(e && atoi(e) == 0) && k4 && g.xs % (4 * k4) == 0;
 }
+// res (k_inverse_trio<K4, M, true, true>): the row is exactly one superstep long and the block length even -- north operands stay in
+// registers.  Taken for batches of up to 2.25 frames per CU -- where the chain wave is what a frame waits for: 32 ... 512 frames
+// -7 ... -10 %, 576 frames -3 %; from 640 frames on the batch is bound by HBM and the form costs 0 ... 1 % (profiles/r05_inverse_ab.log).
+// FPV_TRIO_RES (read per launch: A/B runs, tests): 0 never, 1 whatever the batch size.
+static bool trio_res_ok(const Geom& g, uint32_t k4, uint32_t mblk, uint32_t nframes) {
+  const char* e = getenv("FPV_TRIO_RES");
+  if (e && atoi(e) == 0) return false;
+  if (g.xs != 256 * k4 || (mblk & 1)) return false;
+  return e ? true : 4ull * nframes <= 9ull * device_cus();
+}
+// The instantiation for (in place?, resonant?)
+template <int K4, int MB>
+static auto trio_kernel(bool ip, bool res) -> decltype(&k_inverse_trio<K4, MB, false, false>) {
+  if (ip) {
+    if constexpr (MB % 2 == 0) {
+      if (res) return &k_inverse_trio<K4, MB, true, true>;
+    }
+    return &k_inverse_trio<K4, MB, true, false>;
+  }
+  return &k_inverse_trio<K4, MB, false, false>;
+}
 static uint32_t trio_ring(const Geom& g, uint32_t k4, uint32_t mblk, bool ip = false) {
   const uint32_t S = 256 * k4;
   if (ip) return (3 * mblk + std::max(mblk, (g.xs + 16 + S - 1) / S)) * S;
@@ -3322,8 +3394,7 @@ static uint32_t trio_capacity(const Geom& g, uint32_t k4, uint32_t mblk, bool ip
   if (!*cap_slot) {
     int blocks = 0;
     hipError_t e = hipErrorInvalidValue;
-#define FPV_OCC(K4, MB) if (k4 == K4 && mblk == MB) e = ip ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_inverse_trio<K4, MB, true>, 192, lds) \
-                                                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_inverse_trio<K4, MB, false>, 192, lds);
+#define FPV_OCC(K4, MB) if (k4 == K4 && mblk == MB) { const auto kfn = trio_kernel<K4, MB>(ip, false); e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kfn, 192, lds); }
 #define FPV_OCC3(K4) FPV_OCC(K4, 1) FPV_OCC(K4, 2) FPV_OCC(K4, 4)
     FPV_OCC3(1) FPV_OCC3(2) FPV_OCC3(3) FPV_OCC3(4) FPV_OCC3(5) FPV_OCC3(6)
 #undef FPV_OCC3
@@ -3428,12 +3499,9 @@ hipError_t launch_inverse(const Geom& g, const uint8_t* d_high,
 #endif
 #define FPV_LAUNCH_TRIO(K4, MB)                                                                       \
   if (k4 == K4 && mblk == MB) {                                                                       \
-    if (ip)                                                                                           \
-      k_inverse_trio<K4, MB, true><<<nframes, 192, trio_lds(g, K4, MB, true), s>>>(                   \
-          d_high, d_low, d_dhigh, d_dlow, d_flags, d_frames, FPV_TRIO_GEOM, trio_ring(g, K4, MB, true), d_diag); \
-    else                                                                                              \
-      k_inverse_trio<K4, MB, false><<<nframes, 192, trio_lds(g, K4, MB), s>>>(                        \
-          d_high, d_low, d_dhigh, d_dlow, d_flags, d_frames, FPV_TRIO_GEOM, trio_ring(g, K4, MB), d_diag); \
+    const auto kfn = trio_kernel<K4, MB>(ip, ip && trio_res_ok(g, K4, MB, nframes));                  \
+    kfn<<<nframes, 192, trio_lds(g, K4, MB, ip), s>>>(d_high, d_low, d_dhigh, d_dlow, d_flags, d_frames, FPV_TRIO_GEOM, \
+                                                      trio_ring(g, K4, MB, ip), d_diag);             \
   }
 #define FPV_LAUNCH_TRIO3(K4) FPV_LAUNCH_TRIO(K4, 1) FPV_LAUNCH_TRIO(K4, 2) FPV_LAUNCH_TRIO(K4, 4)
     if (k4 < 1 || k4 > kSpecMaxK4) return hipErrorInvalidValue;

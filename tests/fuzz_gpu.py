@@ -77,6 +77,7 @@ while time.time() - t0 < budget:
     # the three-wave kernel: blocks of 1 / 2 / 4 supersteps, residuals in the ring two blocks ahead (round 5) or in their own slots
     os.environ["FPV_TRIO_BLOCK"] = str(rng.choice(["1", "2", "4"]))
     os.environ["FPV_TRIO_INPLACE"] = str(rng.choice(["1", "0"], p=[0.7, 0.3]))
+    os.environ["FPV_TRIO_RES"] = str(rng.choice(["1", "0"], p=[0.7, 0.3]))   # north operands in registers where the row is one superstep long (256, 1280, 1536 wide here)
     # forward path (read when the context is created): the tile pass with a random tile height where the
     # width allows it (multiples of 64), now and then the streaming kernels instead
     for k in ("FPV_TILE_GROUPS", "FPV_FORWARD", "FPV_TILE8_GROUPS", "FPV_TILE8_ROWS", "FPV_TILE_FGROUP"):

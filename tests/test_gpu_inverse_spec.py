@@ -182,7 +182,7 @@ def test_adversarial_flat_rows_cascade(fpv, oracle):
     p.close()
 
 
-@pytest.mark.parametrize("inplace", ["1", "0"])
+@pytest.mark.parametrize("inplace", ["res", "1", "0"])
 @pytest.mark.parametrize("block", ["1", "2", "4"])
 @pytest.mark.parametrize("xs,ys,n", [(1280, 44, 40), (1024, 28, 24), (1284, 20, 9), (512, 36, 130), (1920, 12, 9), (3072, 8, 5)])
 def test_three_wave_block_lengths(fpv, oracle, block, xs, ys, n, inplace):
@@ -191,13 +191,16 @@ def test_three_wave_block_lengths(fpv, oracle, block, xs, ys, n, inplace):
     reused block after block, more frames than CUs (several workgroups per CU: every chain wave
     claims a SIMD of its own), flags of every kind.  (Under the one-wave kernel of this file's
     fixture the knob changes nothing: the same cases are one more parity run.)
-    Both forms of the kernel: residuals loaded into the ring two blocks ahead (round 5; the default
-    where the width is a multiple of the segment length: every width here but 1284) and, with
-    FPV_TRIO_INPLACE=0, into slots of their own one block ahead.  1920 and 3072 wide: rows longer
-    than a block of one or two supersteps (the ring then holds the row above instead of the block
-    being emitted), segments of 24 pixels."""
-    old_ip = os.environ.get("FPV_TRIO_INPLACE")
-    os.environ["FPV_TRIO_INPLACE"] = inplace
+    All forms of the kernel: residuals loaded into the ring two blocks ahead (round 5; the default
+    where the width is a multiple of the segment length: every width here but 1284) -- with the north
+    operands kept in registers where the row is exactly one superstep long and the block length even
+    ("res", the default: 1280, 1024 and 512 wide here) or read from the ring (FPV_TRIO_RES=0) -- and,
+    with FPV_TRIO_INPLACE=0, residuals in slots of their own one block ahead.  1920 and 3072 wide:
+    rows longer than a block of one or two supersteps (the ring then holds the row above instead of
+    the block being emitted), segments of 24 pixels."""
+    old_ip, old_res = os.environ.get("FPV_TRIO_INPLACE"), os.environ.get("FPV_TRIO_RES")
+    os.environ["FPV_TRIO_INPLACE"] = "0" if inplace == "0" else "1"
+    os.environ["FPV_TRIO_RES"] = "1" if inplace == "res" else "0"
     rng = np.random.default_rng(xs + ys * 3 + n)
     high = rng.integers(0, 256, (n, ys, xs), dtype=np.uint8)
     high[::3] = (rng.integers(0, 40, (len(high[::3]), ys, xs)) == 0) * 7   # long identity runs too
@@ -213,10 +216,11 @@ def test_three_wave_block_lengths(fpv, oracle, block, xs, ys, n, inplace):
             os.environ.pop("FPV_TRIO_BLOCK", None)
         else:
             os.environ["FPV_TRIO_BLOCK"] = old
-        if old_ip is None:
-            os.environ.pop("FPV_TRIO_INPLACE", None)
-        else:
-            os.environ["FPV_TRIO_INPLACE"] = old_ip
+        for k, v in (("FPV_TRIO_INPLACE", old_ip), ("FPV_TRIO_RES", old_res)):
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 def test_chain_simd_claim_fallback_and_recovery(fpv, oracle):

@@ -3438,9 +3438,15 @@ static int inverse_mode(const Geom& g, uint32_t nframes, uint32_t* k4, uint32_t*
     // batch (FPV_TRIO_INPLACE=0: never), in blocks of TWO supersteps unless FPV_TRIO_BLOCK says otherwise: with the
     // residuals that far ahead the shorter block is 1-2 % faster at every batch size (profiles/r05_inverse_ab.log), and it
     // leaves the geometry's own segment length within four workgroups per CU (1280 wide: k4 = 5 up to 1024 frames).
-    const uint32_t ipm = getenv("FPV_TRIO_BLOCK") ? mmax : std::min(mmax, 2u);
-    for (uint32_t kk = g.spec_k4; kk + 1 >= g.spec_k4 && kk >= 1 && mode == 0; kk--)
-      if (nframes <= trio_capacity(g, kk, ipm, true)) { mode = 3; *k4 = kk; *mblk = ipm; *ip = true; }
+    // (where the north operands stay in registers -- trio_res_ok: the chain wave bounds the batch -- and at most two frames share a
+    // CU, blocks of FOUR again: fewer barriers on the critical wave, 3-4 % at 32 ... 512 frames; at 576 frames blocks of two are 2 % ahead.  Loading the next superstep's residuals while a superstep's
+    // passes run was built on top and is 3-15 % SLOWER: the backend waits for such loads in front of the pass loop.)
+    const bool blk_env = getenv("FPV_TRIO_BLOCK") != nullptr;
+    const uint32_t ipm = blk_env ? mmax : std::min(mmax, 2u);
+    for (uint32_t kk = g.spec_k4; kk + 1 >= g.spec_k4 && kk >= 1 && mode == 0; kk--) {
+      if (!blk_env && mmax >= 4 && nframes <= 2 * device_cus() && trio_res_ok(g, kk, 4, nframes) && nframes <= trio_capacity(g, kk, 4, true)) { mode = 3; *k4 = kk; *mblk = 4; *ip = true; }
+      else if (nframes <= trio_capacity(g, kk, ipm, true)) { mode = 3; *k4 = kk; *mblk = ipm; *ip = true; }
+    }
     for (uint32_t mb = mmax; mb >= 1 && mode == 0; mb >>= 1)
       for (uint32_t kk = g.spec_k4; kk + 1 >= g.spec_k4 && kk >= 1 && mode == 0; kk--)
         if (nframes <= trio_capacity(g, kk, mb)) { mode = 3; *k4 = kk; *mblk = mb; }

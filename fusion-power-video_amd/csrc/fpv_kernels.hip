@@ -2377,7 +2377,6 @@ __global__ __launch_bounds__(192) void k_inverse_trio(
   // odd ones: a wave emits what it has loaded itself, so its own counted wait is all the ordering its plane bytes need), and a
   // superstep's bytes come in pieces of 1 KiB (global_load_lds_dwordx4: a quarter of the DMA instructions, each of which costs
   // the issuing wave a hundred clocks or more -- with dword pieces the i/o waves needed the whole phase just to issue theirs).
-  const uint32_t last16 = npix - 16;  // (npix >= 16: the kernel is not chosen for rows shorter than 256 pixels)
   // S bytes of `plane` that belong to superstep t -> dst (wave-uniform).  Returns false when the superstep is the frame's last and
   // short (dword pieces with clamped addresses then: a 16-byte piece could reach past the end of the plane)
   auto dma_span = [&](const uint8_t* plane, uint32_t t, uint8_t* dst) -> bool {

@@ -1268,1484 +1268,7 @@ __global__ __launch_bounds__(64, 2) void k_redo_stream(StreamLaunch) {
   }
 }
 
-// ------------------------------------------------------- inverse predictor --
-
-// One wavefront per frame.  The inverse clamped gradient is ONE serial chain of
-// npix steps (pixel i needs the reconstructed i-1, also across row ends), so
-// the only parallelism is across frames.  Lane 0 walks the chain through an
-// LDS ring of the last `ring` reconstructed bytes; all 64 lanes stage the
-// residuals in and do delta^-1 + recombine + the coalesced uint16 stores.
-constexpr uint32_t kInvChunk = 1024;  // pixels per staging round (multiple of 256)
-
-// ALIGNED: xs and npix are multiples of 4 (every real frame geometry): dword
-// LDS/global accesses.  Otherwise (odd preview planes, odd-sized files from
-// the CPU reference) a byte-granular path with the same structure.
-template <bool ALIGNED>
-__global__ __launch_bounds__(64) void k_inverse(
-    const uint8_t* __restrict__ high, const uint8_t* __restrict__ low,
-    const uint8_t* __restrict__ dhigh, const uint8_t* __restrict__ dlow,
-    const uint8_t* __restrict__ flags, uint16_t* __restrict__ frames, Geom g) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t ring[];
-  const uint32_t frame = blockIdx.x, lane = threadIdx.x;
-  const uint32_t m = g.ring - 1;
-  const size_t fbase = (size_t)frame * g.npix;
-  const uint8_t* hp = high + fbase;
-  const uint8_t* lp = low ? low + fbase : nullptr;
-  uint16_t* outp = frames + fbase;
-  const uint32_t f = flags[frame];
-  const bool use_delta = (f & 1) && dhigh, use_cg = f & 2, no_low = (f & 4) || !lp;
-  const uint32_t xs = g.xs;
-  uint32_t w = 0;  // reconstructed value of pixel i-1 (lane 0)
-
-  for (uint32_t c0 = 0; c0 < g.npix; c0 += kInvChunk) {
-    const uint32_t cn = min(kInvChunk, g.npix - c0);
-    // stage residuals, coalesced
-    if (ALIGNED) {
-      for (uint32_t j = lane * 4; j < cn; j += 256)
-        *reinterpret_cast<uint32_t*>(ring + ((c0 + j) & m)) =
-            *reinterpret_cast<const uint32_t*>(hp + c0 + j);
-    } else {
-      for (uint32_t j = lane; j < cn; j += 64) ring[(c0 + j) & m] = hp[c0 + j];
-    }
-    __syncthreads();
-    if (use_cg && lane == 0) {
-      uint32_t i = c0;
-      // literals (cc:327 starts at xs + 1) and the unaligned head
-      while (i < c0 + cn && (i < xs + 1 || (i & 3) || !ALIGNED)) {
-        uint32_t x = ring[i & m];
-        if (i >= xs + 1) {
-          x = (x + cg_pred(ring[(i - xs) & m], (int)w, ring[(i - xs - 1) & m])) & 0xffu;
-          ring[i & m] = (uint8_t)x;
-        }
-        w = x;
-        i++;
-      }
-      // aligned groups of 4; xs >= 4 keeps a group's north bytes outside itself
-      if (ALIGNED && i < c0 + cn) {
-        uint32_t r4 = *reinterpret_cast<uint32_t*>(ring + (i & m));
-        uint32_t n4 = *reinterpret_cast<uint32_t*>(ring + ((i - xs) & m));
-        uint32_t nw = ring[(i - xs - 1) & m];
-        for (; i < c0 + cn; i += 4) {
-          uint32_t r4n = 0, n4n = 0;
-          const bool more = i + 4 < c0 + cn;
-          if (more && xs >= 8) {  // prefetch: next group's north is older than this group
-            r4n = *reinterpret_cast<uint32_t*>(ring + ((i + 4) & m));
-            n4n = *reinterpret_cast<uint32_t*>(ring + ((i + 4 - xs) & m));
-          }
-          uint32_t o4 = 0;
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            const int nn = (int)byte_of(n4, j);
-            w = (byte_of(r4, j) + cg_pred(nn, (int)w, (int)nw)) & 0xffu;
-            nw = nn;
-            o4 |= w << (8 * j);
-          }
-          *reinterpret_cast<uint32_t*>(ring + (i & m)) = o4;
-          if (more && xs < 8) {
-            r4n = *reinterpret_cast<uint32_t*>(ring + ((i + 4) & m));
-            n4n = *reinterpret_cast<uint32_t*>(ring + ((i + 4 - xs) & m));
-          }
-          r4 = r4n;
-          n4 = n4n;
-        }
-      }
-    }
-    __syncthreads();
-    // delta^-1 + recombine (cc:335-344)
-    if (ALIGNED) {
-      for (uint32_t j = lane * 4; j < cn; j += 256) {
-        uint32_t h4 = *reinterpret_cast<uint32_t*>(ring + ((c0 + j) & m));
-        uint32_t l4 = no_low ? 0u : *reinterpret_cast<const uint32_t*>(lp + c0 + j);
-        if (use_delta) {
-          h4 = add4(h4, *reinterpret_cast<const uint32_t*>(dhigh + c0 + j));
-          l4 = add4(l4, *reinterpret_cast<const uint32_t*>(dlow + c0 + j));
-        }
-        uint2 o;
-        o.x = __builtin_amdgcn_perm(h4, l4, 0x05010400u);  // l0 h0 l1 h1
-        o.y = __builtin_amdgcn_perm(h4, l4, 0x07030602u);  // l2 h2 l3 h3
-        *reinterpret_cast<uint2*>(outp + c0 + j) = o;
-      }
-    } else {
-      for (uint32_t j = lane; j < cn; j += 64) {
-        uint32_t h = ring[(c0 + j) & m], l = no_low ? 0u : lp[c0 + j];
-        if (use_delta) {
-          h = (h + dhigh[c0 + j]) & 0xffu;
-          l = (l + dlow[c0 + j]) & 0xffu;
-        }
-        outp[c0 + j] = (uint16_t)((h << 8) | l);
-      }
-    }
-    // the next round overwrites ring bytes older than xs + 1 + kInvChunk only
-    __syncthreads();
-  }
-}
-
-// Fast inverse (xs % 4 == 0, npix % 4 == 0, xs >= 256).  Still one wavefront
-// per frame and still a serial chain -- that is the algorithm (cc:327-332) --
-// but the chain is cut down to three dependent VALU instructions per pixel.
-// Values are kept as v << 8 in 16-bit lanes, so that "+ r mod 256" is one
-// 16-bit add that wraps by itself:
-//
-//     T = W + D (32-bit, d = n - nw may be negative);  M = med3_i32(N, W, T);
-//     X = add_u16(M, R)
-//
-// Everything that does not depend on the running value W is prepared for a
-// whole 256-pixel chunk by all 64 lanes in parallel and left in LINEAR LDS
-// arrays (one dword per pixel: N, D, R), so the chain issues only 128-bit LDS
-// reads with immediate offsets, the three VALU ops and one 128-bit LDS write
-// per four pixels -- no address arithmetic, no branches.  All lanes run the
-// chain redundantly on wave-uniform data; the other phases are data parallel.
-constexpr uint32_t kInvC = 256;
-constexpr uint32_t kSpecMaxK4 = 6;  // speculative inverse: at most 24 pixels per lane and superstep
-// speculative inverse: passes of a superstep during which run-of-shift-lanes proposals are made;
-// afterwards the plain rule (input := previous lane's output) guarantees the end within 64 passes
-constexpr uint32_t kScanAfter = 4, kScanUntil = 28;  // measured: the unrolled 4-pass loop is the fastest common case
-
-// One-wave workgroups: LDS hand-offs between the phases only need this wave's
-// own LDS operations to have completed.  __syncthreads() would also drain the
-// vector-memory counter and so wait for the global prefetch issued just before.
-__device__ __forceinline__ void wave_lds_sync() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
-}
-
-__device__ __forceinline__ uint32_t inv_px(uint32_t n, uint32_t w, uint32_t d, uint32_t r) {
-  // ClampedGradient (cc:247-252) = the gradient n + w - nw clamped between n and w = the MEDIAN
-  // of the three: one v_med3_i32, no separate min / max.  All operands are v << 8.
-  const int t = (int)w + (int)d;
-  const int a = (int)n, b = (int)w;
-  const int md = max(min(a, b), min(max(a, b), t));   // the backend's median-of-three pattern
-  return as_u32(as_pk((uint32_t)md) + as_pk(r));      // v_pk_add_u16: low lane wraps mod 2^16
-}
-
-// The same three operations spelled out, for the speculative kernels.  The compiler's own choice
-// for the last one is v_pk_add_u16, and it puts an s_nop behind every packed add whose result
-// the next VALU instruction reads (its dst-select forwarding rule): one issue slot in four on
-// the serial path.  v_add_u16 (VOP2) wraps mod 2^16 and writes zeros to the upper half on
-// gfx9-family parts, and no such rule applies to it.
-// Four consecutive chain steps as ONE assembly statement, for the speculative kernels.  Written
-// in C++ the last operation of a step becomes v_pk_add_u16, and the backend puts an s_nop behind
-// every packed add whose result the next VALU instruction reads (its dst-select forwarding
-// rule): one issue slot in four on the serial path.  v_add_u16 (VOP2) wraps mod 2^16 and writes
-// zeros to the upper half on gfx9-family parts, and no such rule applies to it; inside one
-// statement the backend adds nothing (between statements it still does: one s_nop per four
-// pixels instead of one per pixel).
-__device__ __forceinline__ uint32_t inv_px4(const uint32_t* n, uint32_t w, const uint32_t* d, const uint32_t* r, uint32_t* x) {
-#ifdef FPV_INV_PK_ADD
-  x[0] = w = inv_px(n[0], w, d[0], r[0]);
-  x[1] = w = inv_px(n[1], w, d[1], r[1]);
-  x[2] = w = inv_px(n[2], w, d[2], r[2]);
-  x[3] = w = inv_px(n[3], w, d[3], r[3]);
-  return w;
-#else
-  uint32_t x0, x1, x2, x3;
-  asm("v_add_u32_e32 %0, %5, %4\n\tv_med3_i32 %0, %6, %4, %0\n\tv_add_u16_e32 %0, %0, %7\n\t"
-      "v_add_u32_e32 %1, %8, %0\n\tv_med3_i32 %1, %9, %0, %1\n\tv_add_u16_e32 %1, %1, %10\n\t"
-      "v_add_u32_e32 %2, %11, %1\n\tv_med3_i32 %2, %12, %1, %2\n\tv_add_u16_e32 %2, %2, %13\n\t"
-      "v_add_u32_e32 %3, %14, %2\n\tv_med3_i32 %3, %15, %2, %3\n\tv_add_u16_e32 %3, %3, %16"
-      : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3)
-      : "v"(w), "v"(d[0]), "v"(n[0]), "v"(r[0]), "v"(d[1]), "v"(n[1]), "v"(r[1]),
-        "v"(d[2]), "v"(n[2]), "v"(r[2]), "v"(d[3]), "v"(n[3]), "v"(r[3]));
-  x[0] = x0; x[1] = x1; x[2] = x2; x[3] = x3;
-  return x3;
-#endif
-}
-
-// Round 4: the leaner form of the speculative kernels' serial path (FPV_INV_LEAN, default on).
-// A lone chain wave issues one instruction every ~6.3 clocks whatever else its SIMD could take
-// (tools/exp/chain_ilp.hip: a second, independent chain in the same wave gains 8 %, a second WAVE
-// on the SIMD runs at full speed beside it), and at 1000 frames every frame's chain wave has a
-// SIMD to itself: the batch takes what ONE frame's chain takes, so every instruction of that
-// wave's loop counts.  Three cuts, none of which changes a result:
-//   * residuals stay packed: two dwords per four pixels ({0, b0, 0, b2} and {0, b1, 0, b3}: the
-//     bytes as v << 8 halves) instead of four unpacked ones, and the step's last add selects its
-//     half by SDWA (v_add_u16_sdwa src1_sel:WORD_k: same latency as the plain add);
-//   * every lane reruns its segment in every pass -- a lane whose input did not change recomputes
-//     what it had -- so there is no exec masking and no branch around the chain;
-//   * the "is any lane still wrong" test is the compare's lane mask and-ed with the active lanes
-//     (s_and_b64 + scc branch) instead of a ballot of a bool (v_cndmask + v_cmp + vcc branch), and
-//     the DPP needs no zeroed destination.
-#ifndef FPV_INV_LEAN
-#define FPV_INV_LEAN 1
-#endif
-__device__ __forceinline__ uint32_t r_lo(uint32_t rq) { return __builtin_amdgcn_perm(0, rq, 0x020c000cu); }  // {0, b0, 0, b2}
-__device__ __forceinline__ uint32_t r_hi(uint32_t rq) { return rq & 0xff00ff00u; }                             // {0, b1, 0, b3}
-// Four chain steps; rlo / rhi: the four residuals as above.
-__device__ __forceinline__ uint32_t inv_px4w(const uint32_t* n, uint32_t w, const uint32_t* d, uint32_t rlo, uint32_t rhi, uint32_t* x) {
-  uint32_t x0, x1, x2, x3;
-#define FPV_ADDW(X, R, SEL) "v_add_u16_sdwa " X ", " X ", " R " dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:" SEL "\n\t"
-  asm("v_add_u32_e32 %0, %5, %4\n\tv_med3_i32 %0, %6, %4, %0\n\t" FPV_ADDW("%0", "%13", "WORD_0")
-      "v_add_u32_e32 %1, %7, %0\n\tv_med3_i32 %1, %8, %0, %1\n\t" FPV_ADDW("%1", "%14", "WORD_0")
-      "v_add_u32_e32 %2, %9, %1\n\tv_med3_i32 %2, %10, %1, %2\n\t" FPV_ADDW("%2", "%13", "WORD_1")
-      "v_add_u32_e32 %3, %11, %2\n\tv_med3_i32 %3, %12, %2, %3\n\t" FPV_ADDW("%3", "%14", "WORD_1")
-      : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3)
-      : "v"(w), "v"(d[0]), "v"(n[0]), "v"(d[1]), "v"(n[1]), "v"(d[2]), "v"(n[2]), "v"(d[3]), "v"(n[3]), "v"(rlo), "v"(rhi));
-#undef FPV_ADDW
-  x[0] = x0; x[1] = x1; x[2] = x2; x[3] = x3;
-  return x3;
-}
-// The check behind a pass: lane j's input against lane j - 1's output (lane 0: the previous
-// superstep's last pixel).  Returns the mask of active lanes whose input was wrong; *pred_out =
-// the input every lane should have had.
-__device__ __forceinline__ uint64_t chain_check(uint32_t x_last, uint32_t in, uint32_t w_prev, bool lane0, uint64_t active_mask,
-                                                uint32_t* pred_out) {
-  uint32_t pred = (uint32_t)__builtin_amdgcn_update_dpp((int)x_last, (int)x_last, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-  if (lane0) pred = w_prev;
-  *pred_out = pred;
-  return __builtin_amdgcn_uicmp(pred, in, 33 /* ICMP_NE */) & active_mask;
-}
-
-__global__ __launch_bounds__(64) void k_inverse_fast(
-    const uint8_t* __restrict__ high, const uint8_t* __restrict__ low,
-    const uint8_t* __restrict__ dhigh, const uint8_t* __restrict__ dlow,
-    const uint8_t* __restrict__ flags, uint16_t* __restrict__ frames, Geom g) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const uint32_t frame = blockIdx.x, lane = threadIdx.x;
-  const size_t fbase = (size_t)frame * g.npix;
-  const uint8_t* hp = high + fbase;
-  const uint8_t* lp = low ? low + fbase : nullptr;
-  uint16_t* outp = frames + fbase;
-  const uint32_t f = flags[frame];
-  const bool use_delta = (f & 1) && dhigh, use_cg = f & 2, no_low = (f & 4) || !lp;
-  const uint32_t xs = g.xs, npix = g.npix;
-
-  if (!use_cg) {  // no chain: delta^-1 + recombine, 16 pixels per lane and step
-    for (uint32_t o = lane * 16; o < npix; o += 1024) {
-      uint4 h = *reinterpret_cast<const uint4*>(hp + o);
-      uint4 l = no_low ? make_uint4(0, 0, 0, 0) : *reinterpret_cast<const uint4*>(lp + o);
-      if (use_delta) {
-        const uint4 dh = *reinterpret_cast<const uint4*>(dhigh + o);
-        const uint4 dl = *reinterpret_cast<const uint4*>(dlow + o);
-        h.x = add4(h.x, dh.x); h.y = add4(h.y, dh.y); h.z = add4(h.z, dh.z); h.w = add4(h.w, dh.w);
-        l.x = add4(l.x, dl.x); l.y = add4(l.y, dl.y); l.z = add4(l.z, dl.z); l.w = add4(l.w, dl.w);
-      }
-      uint4 a, b;
-      a.x = __builtin_amdgcn_perm(h.x, l.x, 0x05010400u); a.y = __builtin_amdgcn_perm(h.x, l.x, 0x07030602u);
-      a.z = __builtin_amdgcn_perm(h.y, l.y, 0x05010400u); a.w = __builtin_amdgcn_perm(h.y, l.y, 0x07030602u);
-      b.x = __builtin_amdgcn_perm(h.z, l.z, 0x05010400u); b.y = __builtin_amdgcn_perm(h.z, l.z, 0x07030602u);
-      b.z = __builtin_amdgcn_perm(h.w, l.w, 0x05010400u); b.w = __builtin_amdgcn_perm(h.w, l.w, 0x07030602u);
-      *reinterpret_cast<uint4*>(outp + o) = a;
-      *reinterpret_cast<uint4*>(outp + o + 8) = b;
-    }
-    return;
-  }
-
-  // LDS: ring of reconstructed values (v << 8, one dword per pixel), then the
-  // chunk's linear operand arrays and result array.
-  uint32_t* xr = reinterpret_cast<uint32_t*>(smem);
-  const uint32_t m = g.inv_ring - 1;  // ring size in pixels (power of two)
-  uint32_t* nn = xr + g.inv_ring;
-  uint32_t* dd = nn + kInvC;
-  uint32_t* rr = dd + kInvC;
-  uint32_t* xx = rr + kInvC;
-  uint32_t w = 0;
-
-  // Global operands of a chunk (this lane's 4 pixels): fetched ONE CHUNK AHEAD, so
-  // that their latency hides behind the previous chunk's chain.
-  struct Fetch { uint32_t r4, l4, dh4, dl4; };
-  auto fetch = [&](uint32_t c0) {
-    Fetch f = {0, 0, 0, 0};
-    const uint32_t i = c0 + lane * 4;
-    if (i < npix) {
-      f.r4 = *reinterpret_cast<const uint32_t*>(hp + i);
-      if (!no_low) f.l4 = *reinterpret_cast<const uint32_t*>(lp + i);
-      if (use_delta) {
-        f.dh4 = *reinterpret_cast<const uint32_t*>(dhigh + i);
-        f.dl4 = *reinterpret_cast<const uint32_t*>(dlow + i);
-      }
-    }
-    return f;
-  };
-  Fetch cur = fetch(0);
-
-  for (uint32_t c0 = 0; c0 < npix; c0 += kInvC) {
-    const uint32_t cn = min(kInvC, npix - c0);
-    const uint32_t j = lane * 4, i = c0 + j;
-    // prep (all lanes, 4 pixels each)
-    if (j < cn) {
-      const uint32_t r4 = cur.r4;
-      *reinterpret_cast<uint4*>(rr + j) =
-          make_uint4((r4 << 8) & 0xff00u, r4 & 0xff00u, (r4 >> 8) & 0xff00u, (r4 >> 16) & 0xff00u);
-      if (i >= xs + 4) {  // earlier groups go through the head path below
-        const uint4 n4 = *reinterpret_cast<const uint4*>(xr + ((i - xs) & m));
-        const uint32_t nw0 = xr[(i - xs - 1) & m];
-        *reinterpret_cast<uint4*>(nn + j) = n4;
-        *reinterpret_cast<uint4*>(dd + j) = make_uint4(n4.x - nw0, n4.y - n4.x, n4.z - n4.y, n4.w - n4.z);
-      }
-    }
-    const Fetch next = fetch(c0 + kInvC);  // in flight while the chain below runs
-    wave_lds_sync();
-    // chain (wave-uniform)
-    uint32_t jj = 0;
-    for (; jj < cn && c0 + jj < xs + 4; jj += 4) {  // head: literals (cc:327) and the first group
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const uint32_t ii = c0 + jj + k;
-        uint32_t x = rr[jj + k];
-        if (ii >= xs + 1) {
-          const uint32_t n = xr[(ii - xs) & m], nw = xr[(ii - xs - 1) & m];
-          x = inv_px(n, w, n - nw, x);
-        }
-        xr[ii & m] = x;  // the head's own north / north-west come from the ring
-        xx[jj + k] = x;
-        w = x;
-      }
-    }
-    if (jj == 0 && cn == kInvC) {  // the common case: a whole chunk, fully unrolled
-      {
-      // 16 pixels per block; the operands of block q+1 are read from LDS before
-      // block q's chain runs (two static register sets), so no LDS latency is
-      // exposed between blocks.
-      uint4 n4[2][4], d4[2][4], r4[2][4];
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        n4[0][k] = *reinterpret_cast<const uint4*>(nn + 4 * k);
-        d4[0][k] = *reinterpret_cast<const uint4*>(dd + 4 * k);
-        r4[0][k] = *reinterpret_cast<const uint4*>(rr + 4 * k);
-      }
-#pragma unroll
-      for (int q = 0; q < (int)kInvC / 16; q++) {
-        const int a = q & 1, b = a ^ 1;
-        if (q + 1 < (int)kInvC / 16) {
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            n4[b][k] = *reinterpret_cast<const uint4*>(nn + 16 * (q + 1) + 4 * k);
-            d4[b][k] = *reinterpret_cast<const uint4*>(dd + 16 * (q + 1) + 4 * k);
-            r4[b][k] = *reinterpret_cast<const uint4*>(rr + 16 * (q + 1) + 4 * k);
-          }
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          uint4 x4;
-          x4.x = inv_px(n4[a][k].x, w, d4[a][k].x, r4[a][k].x);
-          x4.y = inv_px(n4[a][k].y, x4.x, d4[a][k].y, r4[a][k].y);
-          x4.z = inv_px(n4[a][k].z, x4.y, d4[a][k].z, r4[a][k].z);
-          x4.w = inv_px(n4[a][k].w, x4.z, d4[a][k].w, r4[a][k].w);
-          w = x4.w;
-          *reinterpret_cast<uint4*>(xx + 16 * q + 4 * k) = x4;
-        }
-      }
-      }
-    } else {
-      for (; jj < cn; jj += 4) {
-        const uint4 n4 = *reinterpret_cast<const uint4*>(nn + jj);
-        const uint4 d4 = *reinterpret_cast<const uint4*>(dd + jj);
-        const uint4 r4 = *reinterpret_cast<const uint4*>(rr + jj);
-        uint4 x4;
-        x4.x = inv_px(n4.x, w, d4.x, r4.x);
-        x4.y = inv_px(n4.y, x4.x, d4.y, r4.y);
-        x4.z = inv_px(n4.z, x4.y, d4.z, r4.z);
-        x4.w = inv_px(n4.w, x4.z, d4.w, r4.w);
-        w = x4.w;
-        *reinterpret_cast<uint4*>(xx + jj) = x4;
-      }
-    }
-    wave_lds_sync();
-    // output (all lanes, 4 pixels each): ring update, delta^-1 + recombine (cc:335-344)
-    if (j < cn) {
-      const uint4 x4 = *reinterpret_cast<const uint4*>(xx + j);
-      *reinterpret_cast<uint4*>(xr + (i & m)) = x4;
-      uint32_t h4 = (x4.x >> 8) | (x4.y & 0xff00u) | ((x4.z & 0xff00u) << 8) | ((x4.w & 0xff00u) << 16);
-      uint32_t l4 = cur.l4;
-      if (use_delta) {
-        h4 = add4(h4, cur.dh4);
-        l4 = add4(l4, cur.dl4);
-      }
-      uint2 o;
-      o.x = __builtin_amdgcn_perm(h4, l4, 0x05010400u);
-      o.y = __builtin_amdgcn_perm(h4, l4, 0x07030602u);
-      *reinterpret_cast<uint2*>(outp + i) = o;
-    }
-    cur = next;
-    wave_lds_sync();
-  }
-}
-
-
-// Speculative segmented inverse (xs % 4 == 0, npix % 4 == 0, xs >= 256).
-//
-// The inverse clamped gradient x[i] = r[i] + CG(x[i-xs], x[i-1], x[i-xs-1]) is a
-// serial chain in i (cc:327-332), but ONLY through w = x[i-1]: for a run of up
-// to xs consecutive pixels every north / north-west value belongs to pixels in
-// front of the run and is already final.  So one "superstep" takes S = 64*K
-// consecutive pixels (S <= xs), gives each LANE a segment of K pixels with all
-// its operands in registers, and lets every lane run its segment from a GUESSED
-// incoming w (the pixel above its west neighbour).  The guess is then checked
-// against what the previous lane actually produced; lanes whose input was wrong
-// rerun their segment from the corrected value, until no lane is wrong.
-//
-// This is exact, not approximate: lane 0's input is the final value of the
-// previous superstep, and once lane j's input equals lane j-1's output for all
-// j, every segment is the true chain by induction.  After pass p lanes 0..p-1
-// are final, so at most 64 passes (= the serial chain) are ever needed; on real
-// frames the chain forgets its input within a few pixels whenever w falls into
-// the predictor's flat range [min(n,nw), max(n,nw)], so a wrong guess rarely
-// survives a whole segment and 2-4 passes of K steps replace 64*K serial steps.
-template <int K4>
-__global__ __launch_bounds__(64) void k_inverse_spec(
-    const uint8_t* __restrict__ high, const uint8_t* __restrict__ low,
-    const uint8_t* __restrict__ dhigh, const uint8_t* __restrict__ dlow,
-    const uint8_t* __restrict__ flags, uint16_t* __restrict__ frames, Geom g,
-    uint32_t* __restrict__ pass_count) {
-  constexpr int K = 4 * K4;
-  constexpr uint32_t S = 64u * K;
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  uint8_t* ring = smem;  // reconstructed high bytes, flat index & m
-  const uint32_t frame = blockIdx.x, lane = threadIdx.x;
-  const size_t fbase = (size_t)frame * g.npix;
-  const uint8_t* hp = high + fbase;
-  const uint8_t* lp = low ? low + fbase : nullptr;
-  uint16_t* outp = frames + fbase;
-  const uint32_t f = flags[frame];
-  const bool use_delta = (f & 1) && dhigh, use_cg = f & 2, no_low = (f & 4) || !lp;
-  const uint32_t xs = g.xs, npix = g.npix, m = g.spec_ring - 1;
-
-  // delta^-1 + recombine (cc:335-344) of the 4 pixels at flat index i
-  auto emit4 = [&](uint32_t i, uint32_t h4, uint32_t l4, uint32_t dh4, uint32_t dl4) {
-    if (use_delta) {
-      h4 = add4(h4, dh4);
-      l4 = add4(l4, dl4);
-    }
-    uint2 o;
-    o.x = __builtin_amdgcn_perm(h4, l4, 0x05010400u);
-    o.y = __builtin_amdgcn_perm(h4, l4, 0x07030602u);
-    *reinterpret_cast<uint2*>(outp + i) = o;
-  };
-
-  if (!use_cg) {
-    // No chain at all: delta^-1 + recombine.  The frame still belongs to this one
-    // wave, so the loads of 4 steps (4096 pixels) are issued back to back before
-    // anything is consumed (16 KiB in flight per wave), which
-    // keeps such a frame well below the time of a clamped-gradient frame.
-    constexpr int U = 4;
-    uint32_t base = 0;
-    for (; base + U * 1024 <= npix; base += U * 1024) {
-      uint4 h[U], l[U], dh[U], dl[U];
-#pragma unroll
-      for (int u = 0; u < U; u++) h[u] = *reinterpret_cast<const uint4*>(hp + base + u * 1024 + lane * 16);
-      if (!no_low) {
-#pragma unroll
-        for (int u = 0; u < U; u++) l[u] = *reinterpret_cast<const uint4*>(lp + base + u * 1024 + lane * 16);
-      } else {
-#pragma unroll
-        for (int u = 0; u < U; u++) l[u] = make_uint4(0, 0, 0, 0);
-      }
-      if (use_delta) {
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-          dh[u] = *reinterpret_cast<const uint4*>(dhigh + base + u * 1024 + lane * 16);
-          dl[u] = *reinterpret_cast<const uint4*>(dlow + base + u * 1024 + lane * 16);
-        }
-      } else {
-#pragma unroll
-        for (int u = 0; u < U; u++) dh[u] = dl[u] = make_uint4(0, 0, 0, 0);
-      }
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        const uint32_t hh[4] = {add4(h[u].x, dh[u].x), add4(h[u].y, dh[u].y), add4(h[u].z, dh[u].z), add4(h[u].w, dh[u].w)};
-        const uint32_t ll[4] = {add4(l[u].x, dl[u].x), add4(l[u].y, dl[u].y), add4(l[u].z, dl[u].z), add4(l[u].w, dl[u].w)};
-        uint4 a, b2;
-        a.x = __builtin_amdgcn_perm(hh[0], ll[0], 0x05010400u); a.y = __builtin_amdgcn_perm(hh[0], ll[0], 0x07030602u);
-        a.z = __builtin_amdgcn_perm(hh[1], ll[1], 0x05010400u); a.w = __builtin_amdgcn_perm(hh[1], ll[1], 0x07030602u);
-        b2.x = __builtin_amdgcn_perm(hh[2], ll[2], 0x05010400u); b2.y = __builtin_amdgcn_perm(hh[2], ll[2], 0x07030602u);
-        b2.z = __builtin_amdgcn_perm(hh[3], ll[3], 0x05010400u); b2.w = __builtin_amdgcn_perm(hh[3], ll[3], 0x07030602u);
-        uint16_t* op = outp + base + u * 1024 + lane * 16;
-        *reinterpret_cast<uint4*>(op) = a;
-        *reinterpret_cast<uint4*>(op + 8) = b2;
-      }
-    }
-    for (uint32_t i = base + lane * 4; i < npix; i += 256)  // tail: fewer than 4096 pixels
-      emit4(i, *reinterpret_cast<const uint32_t*>(hp + i),
-            no_low ? 0u : *reinterpret_cast<const uint32_t*>(lp + i),
-            use_delta ? *reinterpret_cast<const uint32_t*>(dhigh + i) : 0u,
-            use_delta ? *reinterpret_cast<const uint32_t*>(dlow + i) : 0u);
-    return;
-  }
-
-  // Head: the first xs + 1 pixels are literals (cc:327 starts at xs + 1); pixels
-  // xs+1 .. xs+3 are walked serially so that the supersteps start 4-aligned.
-  const uint32_t head = min(xs + 4, npix);
-  for (uint32_t o = lane * 4; o < head; o += 256)
-    *reinterpret_cast<uint32_t*>(ring + (o & m)) = *reinterpret_cast<const uint32_t*>(hp + o);
-  wave_lds_sync();
-  {
-    int w = ring[xs & m];
-    for (uint32_t i = xs + 1; i < head; i++) {
-      const int x = (ring[i & m] + cg_pred(ring[(i - xs) & m], w, ring[(i - xs - 1) & m])) & 0xff;
-      ring[i & m] = (uint8_t)x;  // every lane writes the same value
-      w = x;
-    }
-  }
-  wave_lds_sync();
-  for (uint32_t o = lane * 4; o < head; o += 256)
-    emit4(o, *reinterpret_cast<const uint32_t*>(ring + (o & m)),
-          no_low ? 0u : *reinterpret_cast<const uint32_t*>(lp + o),
-          use_delta ? *reinterpret_cast<const uint32_t*>(dhigh + o) : 0u,
-          use_delta ? *reinterpret_cast<const uint32_t*>(dlow + o) : 0u);
-  uint32_t w_prev = (uint32_t)ring[(head - 1) & m] << 8;  // wave-uniform: final x[s-1] << 8
-
-  // Every global access of the superstep loop is unconditional (clamped index,
-  // planes that do not exist replaced by a readable dummy and masked to zero), so
-  // that the loads stay in flight behind counted vmcnt waits instead of being
-  // drained at a branch.  Only the last, partial superstep predicates its stores.
-  const uint8_t* lsrc = no_low ? hp : lp;
-  const uint8_t* dhsrc = use_delta ? dhigh : hp;
-  const uint8_t* dlsrc = use_delta ? dlow : hp;
-  const uint32_t lmask = no_low ? 0u : ~0u, dmask = use_delta ? ~0u : 0u;
-  const uint32_t last4 = npix - 4;  // npix % 4 == 0 and npix >= head >= 4
-
-  // residual dwords of this lane's segment, fetched one superstep ahead
-  uint32_t rq[K4];
-  auto fetch_r = [&](uint32_t s0, uint32_t* q) {
-#pragma unroll
-    for (int t = 0; t < K4; t++) {
-      const uint32_t i = s0 + lane * K + 4 * t;
-      const uint32_t v = *reinterpret_cast<const uint32_t*>(hp + min(i, last4));
-      q[t] = i < npix ? v : 0u;
-    }
-  };
-  fetch_r(head, rq);
-  // Operands of the output phase (low plane, delta planes: coalesced, 4 pixels per lane and
-  // round) are fetched ONE SUPERSTEP AHEAD, and issued in FRONT of the previous superstep's
-  // stores: a vector-memory wait is in issue order, so a load queued behind stores would
-  // make its consumer wait for the stores' acknowledgements too (with the loads issued at
-  // the top of their own superstep a third of the wave's cycles went into such waits).
-  uint32_t l4n[K4], dh4n[K4], dl4n[K4];
-  auto fetch_out = [&](uint32_t s0) {
-#pragma unroll
-    for (int t = 0; t < K4; t++) {
-      const uint32_t ic = min(s0 + (t * 64 + lane) * 4, last4);
-      l4n[t] = *reinterpret_cast<const uint32_t*>(lsrc + ic);   // raw: masked where they are consumed, so that
-      dh4n[t] = *reinterpret_cast<const uint32_t*>(dhsrc + ic);  // nothing touches a loaded value (= waits for
-      dl4n[t] = *reinterpret_cast<const uint32_t*>(dlsrc + ic);  // it) before the output phase
-    }
-  };
-  fetch_out(head);
-  uint32_t npass = 0, maxpass = 0;
-
-  auto superstep = [&](uint32_t s0, auto full_tag) {
-    constexpr bool FULL = decltype(full_tag)::value;
-    const uint32_t start = s0 + lane * K;
-    const bool active = FULL || start < npix;
-    // segment operands into registers, everything as v << 8
-#if FPV_INV_LEAN
-    uint32_t N[K], D[K], X[K], RL[K4], RH[K4];  // residuals stay packed: see inv_px4w
-#else
-    uint32_t N[K], D[K], R[K], X[K];
-#endif
-    uint32_t guess;
-    {
-      const uint32_t nb = start - xs - 4;  // dword holding the north-west of the first pixel
-      uint32_t nd[K4 + 1];
-#pragma unroll
-      for (int t = 0; t <= K4; t++) nd[t] = *reinterpret_cast<const uint32_t*>(ring + ((nb + 4 * t) & m));
-      uint32_t prev = __builtin_amdgcn_perm(0, nd[0], 0x0c0c030cu);
-      guess = prev;  // x[start - 1 - xs] << 8
-#pragma unroll
-      for (int t = 0; t < K4; t++) {
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-          const uint32_t sel = 0x0c0c000cu | ((uint32_t)b << 8);
-          const uint32_t n = __builtin_amdgcn_perm(0, nd[t + 1], sel);
-          N[4 * t + b] = n;
-          D[4 * t + b] = n - prev;
-#if !FPV_INV_LEAN
-          R[4 * t + b] = __builtin_amdgcn_perm(0, rq[t], sel);
-#endif
-          prev = n;
-        }
-#if FPV_INV_LEAN
-        RL[t] = r_lo(rq[t]);
-        RH[t] = r_hi(rq[t]);
-#endif
-      }
-    }
-    fetch_r(s0 + S, rq);  // next superstep's residuals (rq was consumed above)
-
-    // Passes: the first one runs every lane from its guess (lane 0 from the known
-    // value), the following ones only the lanes whose input turned out wrong.  ONE
-    // copy of the chain code serves all passes, so X[] stays in fixed registers.
-    //
-    // Long correction chains come from segments whose north pixels are all equal
-    // (d == 0 everywhere): there the predictor is the identity, the segment maps
-    // its input w to w + sum(r) for EVERY w, and a wrong guess is never forgotten.
-    // When a superstep is still wrong after kScanAfter passes, such "shift" lanes
-    // are detected and the inputs of whole runs of them are proposed at once by a
-    // prefix scan over the lanes (shift lanes add their sum, other lanes contribute
-    // their current output).  A proposal is only ever a proposal: the loop still
-    // ends on the same check (every input equals the previous lane's actual
-    // output), so exactness does not depend on it.
-    uint32_t in = lane == 0 ? w_prev : guess;
-    bool run = true;
-    const uint32_t npass0 = npass;
-    bool settled = false;
-#if FPV_INV_LEAN
-    const uint64_t active_mask = __builtin_amdgcn_ballot_w64(active);
-    for (uint32_t round = 0; round < kScanAfter; round++) {  // the common case ends in here
-      uint32_t w = in, pred;  // every lane, every pass: a lane whose input did not change recomputes what it had
-#pragma unroll
-      for (int k = 0; k < K; k += 4) w = inv_px4w(N + k, w, D + k, RL[k / 4], RH[k / 4], X + k);
-      npass++;
-      if (!chain_check(X[K - 1], in, w_prev, lane == 0, active_mask, &pred)) { settled = true; break; }
-      in = pred;
-    }
-#else
-    for (uint32_t round = 0; round < kScanAfter; round++) {  // the common case ends in here
-      if (run) {
-        uint32_t w = in;
-#pragma unroll
-        for (int k = 0; k < K; k += 4) w = inv_px4(N + k, w, D + k, R + k, X + k);
-      }
-      npass++;
-      uint32_t pred = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)X[K - 1], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-      if (lane == 0) pred = w_prev;
-      run = active && pred != in;
-      if (!__builtin_amdgcn_ballot_w64(run)) { settled = true; break; }
-      in = pred;  // lanes that do not rerun have pred == in already
-    }
-#endif
-    if (__builtin_expect(!settled, 0)) {
-      // Still wrong after kScanAfter passes: a long correction chain.  Its own copy
-      // of the pass loop, so that nothing of it burdens the loop above.
-      uint32_t all, ord = 0, sum = 0;
-      asm volatile("v_mov_b32 %0, -1" : "=v"(all));  // keeps the compiler from hoisting the 2K ops below
-#if FPV_INV_LEAN
-      uint32_t R[K];
-#pragma unroll
-      for (int k = 0; k < K; k += 4) {
-        R[k] = RL[k / 4] & 0xffffu; R[k + 1] = RH[k / 4] & 0xffffu; R[k + 2] = RL[k / 4] >> 16; R[k + 3] = RH[k / 4] >> 16;
-      }
-      run = true;  // (the first pass in here reruns every lane, like the loop above)
-#endif
-#pragma unroll
-      for (int k = 0; k < K; k++) { ord = max(ord, D[k] & all); sum += R[k] & all; }
-      const bool is_shift = ord == 0 && lane != 0;  // lane 0 is final after the first pass: a constant
-      const uint32_t ssum = sum & 0xffffu;
-      for (;;) {
-        if (run) {
-          uint32_t w = in;
-#pragma unroll
-          for (int k = 0; k < K; k += 4) w = inv_px4(N + k, w, D + k, R + k, X + k);
-        }
-        npass++;
-        uint32_t pred = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)X[K - 1], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-        if (lane == 0) pred = w_prev;
-        const bool bad = active && pred != in;
-        if (!__builtin_amdgcn_ballot_w64(bad)) break;
-        uint32_t next_in = pred;
-        if (npass - npass0 < kScanUntil) {  // wave-uniform
-          // inclusive scan of the lanes' functions: CONST(c) or SHIFT(s); lane 0 is CONST
-          uint32_t isc = is_shift ? 0u : 1u, v = is_shift ? ssum : X[K - 1];
-#pragma unroll
-          for (int dlt = 1; dlt < 64; dlt <<= 1) {
-            const uint32_t isc_l = __shfl_up(isc, dlt, 64), v_l = __shfl_up(v, dlt, 64);
-            if (lane >= (uint32_t)dlt && !isc) {
-              v = (v + v_l) & 0xffffu;
-              isc = isc_l;
-            }
-          }
-          next_in = __shfl_up(v, 1, 64);  // the consistent output of lane j-1
-          if (lane == 0) next_in = w_prev;
-        }
-        run = active && next_in != in;  // bad somewhere implies run somewhere
-        in = next_in;
-      }
-    }
-    maxpass = max(maxpass, npass - npass0);
-    w_prev = (uint32_t)__builtin_amdgcn_readlane((int)X[K - 1], 63);
-
-    // reconstructed bytes into the ring (north of the next row, source of the output phase)
-#pragma unroll
-    for (int t = 0; t < K4; t++) {
-      const uint32_t o = __builtin_amdgcn_perm(X[4 * t + 1], X[4 * t], 0x0c0c0501u) |
-                         __builtin_amdgcn_perm(X[4 * t + 3], X[4 * t + 2], 0x05010c0cu);
-      *reinterpret_cast<uint32_t*>(ring + ((start + 4 * t) & m)) = o;
-    }
-    wave_lds_sync();
-    uint32_t h4[K4];
-#pragma unroll
-    for (int t = 0; t < K4; t++)
-      h4[t] = *reinterpret_cast<const uint32_t*>(ring + ((s0 + (t * 64 + lane) * 4) & m));
-    uint2 px[K4];
-#pragma unroll
-    for (int t = 0; t < K4; t++) {  // delta^-1 + recombine (cc:335-344); absent planes are zeros
-      const uint32_t hh = add4(h4[t], dh4n[t] & dmask), ll = add4(l4n[t] & lmask, dl4n[t] & dmask);
-      px[t].x = __builtin_amdgcn_perm(hh, ll, 0x05010400u);
-      px[t].y = __builtin_amdgcn_perm(hh, ll, 0x07030602u);
-    }
-    fetch_out(s0 + S);  // the next superstep's operands (the registers are free now), in front of this one's stores
-#pragma unroll
-    for (int t = 0; t < K4; t++) {
-      const uint32_t i = s0 + (t * 64 + lane) * 4;
-      if (FULL || i < npix) *reinterpret_cast<uint2*>(outp + i) = px[t];
-    }
-    wave_lds_sync();
-  };
-
-  uint32_t s = head;
-  for (; s + S <= npix; s += S) superstep(s, std::true_type());
-  if (s < npix) superstep(s, std::false_type());
-  if (pass_count && lane == 0) {  // diagnostics: supersteps and passes (bench / tests)
-    atomicAdd(&pass_count[0], (npix - head + S - 1) / S);
-    atomicAdd(&pass_count[1], npass);
-    atomicMax(&pass_count[2], npass);      // the slowest frame bounds a launch with one wave per SIMD
-    atomicMax(&pass_count[3], maxpass);    // longest verification chain seen in one superstep
-  }
-}
-
-
-// k_inverse_trio<K4, M>: the speculative segmented inverse (see k_inverse_spec) with the
-// work of a frame split over THREE waves of one workgroup, by role:
-//
-//   chain wave      north bytes + residuals from LDS -> operands -> passes ->
-//                   reconstructed bytes into the LDS ring.  Issues no global memory
-//                   instruction inside its loop: its instruction stream is the frame's
-//                   critical path and nothing else.  Which of the three waves it is, the
-//                   workgroup decides at run time: the one on a SIMD that no other
-//                   frame's chain wave is on (g_chain_simd_mask).
-//   two i/o waves   move every byte the frame needs from HBM straight into LDS
-//                   (global_load_lds: no registers, so nothing of a load has to be touched
-//                   before it is used): residuals for the chain wave, low plane and delta
-//                   planes for themselves; and run the output phase: ring + staged planes
-//                   -> delta^-1 + recombine -> coalesced stores.  Each owns half of the
-//                   64-lane x 4-byte groups of every superstep.
-//
-// The waves meet once per BLOCK of M supersteps (one workgroup barrier, a bare s_barrier
-// behind an LDS-only wait, so loads stay in flight across it): in phase b the chain wave runs
-// block b back to back; an i/o wave issues the residual loads of block b + 1, emits block
-// b - 1, issues the plane loads of block b into the slots it has just read, and retires
-// everything but those plane loads with a counted vmcnt before the barrier.  DESIGN.md section
-// 4 has the measurements behind each of these choices.
-
-// 64 lanes x 4 bytes from per-lane global addresses into LDS at dst + 4 * lane.
-__device__ __forceinline__ void dma4(const uint8_t* src, uint8_t* dst_wave_uniform) {
-  __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t*>(src),
-                                   reinterpret_cast<uint32_t*>(dst_wave_uniform), 4, 0, 0);
-}
-
-// 64 lanes x 16 bytes (1 KiB per instruction, gfx950's global_load_lds_dwordx4) into LDS at dst + 16 * lane.
-__device__ __forceinline__ void dma16(const uint8_t* src, uint8_t* dst_wave_uniform) {
-  __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t*>(src),
-                                   reinterpret_cast<uint32_t*>(dst_wave_uniform), 16, 0, 0);
-}
-
-// SIMDs with a chain wave of k_inverse_trio on them, one word per CU (index: XCC, SE, SH, CU of
-// HW_ID), bits 0..3.  Device-wide on purpose: the claim is about the physical SIMD, whichever
-// context or stream the other frame belongs to.
-constexpr uint32_t kChainSimdWords = 4096;
-__device__ uint32_t g_chain_simd_mask[kChainSimdWords];
-
-// IP (round 5, "in place"): the residual bytes are loaded straight into the RING, at the place where the chain wave will
-// put the pixel it makes of them, TWO blocks ahead of the chain wave instead of one; the low plane has two buffers and is
-// loaded a whole phase ahead.  Measured with clock stamps (tools/exp/inv_waits.py, 1000 frames): the chain wave stood at the
-// barrier for 12 % of its life and an i/o wave waited 9 % for its plane bytes and 10 % for residuals and store
-// acknowledgements in front of the barrier -- each side late for the other in turn, one block of slack being less than
-// a loaded HBM round trip.  With the residuals two blocks ahead nothing is waited for in front of the barrier at all, and
-// what the i/o wave waits for at the top of a phase was issued a whole phase earlier (the delta planes' bytes, L2 hits, half
-// a phase).  The ring is a whole number of supersteps (not a power of two: the slot of a superstep is a counter), and
-// supersteps start at ring offsets that are multiples of S, so a DMA piece (256 bytes) never wraps.  Needs xs % K == 0
-// (a lane's north bytes then never straddle the ring's end).
-// RES (round 5, with IP and an even M): the row is exactly one superstep long (xs == 256 K4: 1280 wide at K4 = 5, 1024 at 4, 1536
-// at 6).  The bytes above a lane's segment are then the pixels the SAME lane made one superstep earlier: they stay in registers
-// (two sets taking turns), the chain wave reads no north bytes from the ring and unpacks none.
-template <int K4, int M, bool IP = false, bool RES = false>
-__global__ __launch_bounds__(192) void k_inverse_trio(
-    const uint8_t* __restrict__ high, const uint8_t* __restrict__ low,
-    const uint8_t* __restrict__ dhigh, const uint8_t* __restrict__ dlow,
-    const uint8_t* __restrict__ flags, uint16_t* __restrict__ frames, Geom g,
-    uint32_t ring_bytes, uint32_t* __restrict__ pass_count) {
-  constexpr int K = 4 * K4;
-  constexpr uint32_t S = 64u * K;
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  uint8_t* ring = smem;                 // reconstructed high bytes: pixel i at rix(i) = (i - 4) & m  (IP: (i - head) mod ring_bytes)
-  uint8_t* rbuf = smem + ring_bytes;    // residual bytes of superstep t at rbuf + (t & (2 M - 1)) * S  (IP: none, they are in the ring)
-  // low / delta-high / delta-low bytes of the q-th superstep of a block at lbuf + (q * 3 + plane) * S
-  // (IP: at lbuf + q * 4 S: low of even blocks, low of odd blocks, delta high, delta low)
-  uint8_t* lbuf = IP ? rbuf : rbuf + 2 * M * S;
-  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  uint32_t role = wave;  // 0 chain, 1 and 2 i/o; frames with a chain reassign it below (the SIMD claim)
-  const uint32_t frame = blockIdx.x, lane = threadIdx.x & 63;
-#ifdef FPV_EXP_PITCH  // experiments only (tools/exp/inv_pitch.py): planes / pixels of consecutive frames at a padded pitch
-  const size_t fbase = (size_t)frame * (g.npix + g.strip_rows), fbase_out = (size_t)frame * (g.npix + g.strips);
-#else
-  const size_t fbase = (size_t)frame * g.npix, fbase_out = fbase;
-#endif
-  const uint8_t* hp = high + fbase;
-  const uint8_t* lp = low ? low + fbase : nullptr;
-  uint16_t* outp = frames + fbase_out;
-  const uint32_t f = flags[frame];
-  const bool use_delta = (f & 1) && dhigh, use_cg = f & 2, no_low = (f & 4) || !lp;
-  const uint32_t xs = g.xs, npix = g.npix, m = ring_bytes - 1;
-  const uint32_t head = min(xs + 4, npix);
-  const uint32_t nslots = ring_bytes / S;  // IP: the ring is nslots supersteps long; superstep t lies at (t mod nslots) * S
-  // ring offset of pixel i (see the chain wave's 128-bit accesses).  IP: the general form, used outside the loops only
-  // (pixels in front of the first superstep lie at the ring's end: ring_bytes >= head)
-  auto rix = [&](uint32_t i) { return IP ? (i + ring_bytes - head) % ring_bytes : (i - 4u) & m; };
-
-  // delta^-1 + recombine (cc:335-344) of 4 pixels; planes that do not exist come as zeros
-  auto emit4 = [&](uint32_t i, uint32_t h4, uint32_t l4, uint32_t dh4, uint32_t dl4) {
-#ifdef FPV_EXP_NOADD4  // timing experiment only (wrong pixels): the i/o waves without their byte adds
-    const uint32_t hh = h4 ^ dh4, ll = l4 ^ dl4;
-#else
-    const uint32_t hh = add4(h4, dh4), ll = add4(l4, dl4);
-#endif
-    uint2 o;
-    o.x = __builtin_amdgcn_perm(hh, ll, 0x05010400u);
-    o.y = __builtin_amdgcn_perm(hh, ll, 0x07030602u);
-#ifdef FPV_EXP_NOSTORE  // timing experiment only: no pixel stores (except impossible values)
-    if (o.x == 0x12345678u && o.y == 0x9abcdef0u)
-#endif
-    *reinterpret_cast<uint2*>(outp + i) = o;
-  };
-  const uint8_t* lsrc = no_low ? hp : lp;  // readable dummies for planes that do not exist
-  const uint8_t* dhsrc = use_delta ? dhigh : hp;
-  const uint8_t* dlsrc = use_delta ? dlow : hp;
-  const uint32_t lmask = no_low ? 0u : ~0u, dmask = use_delta ? ~0u : 0u;
-  const uint32_t last4 = npix - 4;  // npix % 4 == 0, npix >= 4
-
-  if (!use_cg) {  // no chain: the three waves stream the frame, 4096 pixels per wave and turn
-    constexpr int U = 4;
-    uint32_t base = role * (U * 1024);
-    for (; base + U * 1024 <= npix; base += 3 * U * 1024) {
-      uint4 h[U], l[U], dh[U], dl[U];
-#pragma unroll
-      for (int u = 0; u < U; u++) h[u] = *reinterpret_cast<const uint4*>(hp + base + u * 1024 + lane * 16);
-      if (!no_low) {
-#pragma unroll
-        for (int u = 0; u < U; u++) l[u] = *reinterpret_cast<const uint4*>(lp + base + u * 1024 + lane * 16);
-      } else {
-#pragma unroll
-        for (int u = 0; u < U; u++) l[u] = make_uint4(0, 0, 0, 0);
-      }
-      if (use_delta) {
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-          dh[u] = *reinterpret_cast<const uint4*>(dhigh + base + u * 1024 + lane * 16);
-          dl[u] = *reinterpret_cast<const uint4*>(dlow + base + u * 1024 + lane * 16);
-        }
-      } else {
-#pragma unroll
-        for (int u = 0; u < U; u++) dh[u] = dl[u] = make_uint4(0, 0, 0, 0);
-      }
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        const uint32_t hh[4] = {add4(h[u].x, dh[u].x), add4(h[u].y, dh[u].y), add4(h[u].z, dh[u].z), add4(h[u].w, dh[u].w)};
-        const uint32_t ll[4] = {add4(l[u].x, dl[u].x), add4(l[u].y, dl[u].y), add4(l[u].z, dl[u].z), add4(l[u].w, dl[u].w)};
-        uint4 a, b2;
-        a.x = __builtin_amdgcn_perm(hh[0], ll[0], 0x05010400u); a.y = __builtin_amdgcn_perm(hh[0], ll[0], 0x07030602u);
-        a.z = __builtin_amdgcn_perm(hh[1], ll[1], 0x05010400u); a.w = __builtin_amdgcn_perm(hh[1], ll[1], 0x07030602u);
-        b2.x = __builtin_amdgcn_perm(hh[2], ll[2], 0x05010400u); b2.y = __builtin_amdgcn_perm(hh[2], ll[2], 0x07030602u);
-        b2.z = __builtin_amdgcn_perm(hh[3], ll[3], 0x05010400u); b2.w = __builtin_amdgcn_perm(hh[3], ll[3], 0x07030602u);
-        uint16_t* op = outp + base + u * 1024 + lane * 16;
-        *reinterpret_cast<uint4*>(op) = a;
-        *reinterpret_cast<uint4*>(op + 8) = b2;
-      }
-    }
-    // tail (fewer than 3 x 4096 pixels): the first pixel no wave has covered, split by thread
-    const uint32_t done = (npix / (U * 1024)) * (U * 1024);
-    for (uint32_t i = done + threadIdx.x * 4; i < npix; i += 192 * 4)
-      emit4(i, *reinterpret_cast<const uint32_t*>(hp + i),
-            *reinterpret_cast<const uint32_t*>(lsrc + i) & lmask,
-            *reinterpret_cast<const uint32_t*>(dhsrc + i) & dmask,
-            *reinterpret_cast<const uint32_t*>(dlsrc + i) & dmask);
-    return;
-  }
-
-  const uint32_t nsteps = (npix - head + S - 1) / S;
-  const uint32_t nblocks = (nsteps + M - 1) / M;  // the waves meet once per block of M supersteps
-
-  // Which of the three waves runs the chain?  The one whose SIMD no other frame's chain wave
-  // is on.  A chain wave issues on three of four issue slots of its SIMD; two of them on one
-  // SIMD take a quarter longer each, and the batch ends with its slowest frame: measured with
-  // the chain always on wave 0 (tools/exp/inv_placement.py, 1000 frames) one CU in 250 gave two
-  // workgroups the same starting SIMD, and those two frames ran 2.02 M clocks where the mean was
-  // 1.62 M and every other frame stayed under 1.74 M -- a seventh of the batch time for one pair.
-  // Per CU a word in device memory holds the SIMDs taken; a workgroup claims a free one among
-  // those its waves are on (returning atomics, once per frame) and gives it back at the end.
-  uint32_t* ctl = reinterpret_cast<uint32_t*>(IP ? lbuf + 4 * M * S : rbuf + 5 * M * S);  // 8 words behind the plane slots
-  uint32_t claimed_simd = 4, cu_index = 0;
-  {
-    uint32_t hw, xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    const uint32_t simd = (hw >> 4) & 3;
-    cu_index = ((xcc & 0xf) << 8 | ((hw >> 8) & 0xff)) & (kChainSimdWords - 1);  // XCC, SE, SH, CU
-    if (lane == 0) ctl[wave] = simd;
-    lds_barrier();
-    if (wave == 0) {
-      uint32_t pick = 0, got = 4;
-      if (lane == 0) {
-#ifndef FPV_NO_CHAIN_CLAIM
-        for (uint32_t c = 0; c < 3 && got == 4; c++) {
-          const uint32_t sd = ctl[c];
-          if (!(atomicOr(&g_chain_simd_mask[cu_index], 1u << sd) & (1u << sd))) { pick = c; got = sd; }
-        }
-#endif
-        ctl[4] = pick;
-        ctl[5] = got;
-      }
-    }
-    lds_barrier();
-    const uint32_t pick = ctl[4];
-    claimed_simd = ctl[5];
-    role = wave == pick ? 0u : wave == (pick + 1) % 3 ? 1u : 2u;
-    role = __builtin_amdgcn_readfirstlane(role);
-  }
-#ifdef FPV_EXP_HWID
-  const uint64_t exp_hw_t0 = clock64();
-#endif
-  uint32_t w_prev = 0, npass = 0, maxpass = 0;  // chain wave
-#ifdef FPV_EXP_WAITS  // experiment: where the waves of a frame wait (shader clocks, summed over the frame)
-  uint64_t exp_bar = 0, exp_t0 = clock64(), exp_top = 0, exp_pre = 0;  // at the barriers; i/o: in the wait for the planes (top of a phase), in the wait in front of the barrier
-#endif
-#ifndef FPV_NO_CHAIN_PRIO
-  // The chain wave is the frame's critical path; on its SIMD it competes with i/o waves of
-  // other frames.  Issue arbitration goes by priority first, then age (MI355X_MICROARCH.md).
-#ifndef FPV_EXP_CHAIN_PRIO  // experiments (profiles/r05_inverse_ab.log): other priorities for the two roles
-#define FPV_EXP_CHAIN_PRIO 3
-#endif
-  if (role == 0) __builtin_amdgcn_s_setprio(FPV_EXP_CHAIN_PRIO);
-#endif
-#ifdef FPV_EXP_IO_PRIO
-  if (role != 0) __builtin_amdgcn_s_setprio(FPV_EXP_IO_PRIO);
-#endif
-
-  // i/o wave 1 owns the k-groups [0, KA) of every superstep (64 lanes x 4 bytes each), i/o
-  // wave 2 the groups [KA, K4): both work in every block, half of it each.  Indices are clamped
-  // into the frame; what lies beyond the last pixel is never emitted and never anybody's north.
-  constexpr int KA = (K4 + 1) / 2;
-  auto dma_r = [&](uint32_t t, auto k0, auto k1) {  // residuals of superstep t -> LDS (dword k * 64 + lane)
-#pragma unroll
-    for (int k = k0; k < k1; k++)
-      dma4(hp + min(head + t * S + (k * 64 + lane) * 4, last4), rbuf + (t & (2 * M - 1)) * S + k * 256);
-  };
-  auto dma_r_ip = [&](uint32_t t, uint32_t slot, auto k0, auto k1) {  // IP: into the ring, superstep t's place
-#pragma unroll
-    for (int k = k0; k < k1; k++)
-      dma4(hp + min(head + t * S + (k * 64 + lane) * 4, last4), ring + slot * S + k * 256);
-  };
-  using IC0 = std::integral_constant<int, 0>;
-  using ICA = std::integral_constant<int, KA>;
-  using ICK = std::integral_constant<int, K4>;
-
-  if (role == 0) {
-    // Head: the first xs + 1 pixels are literals (cc:327 starts at xs + 1); pixels
-    // xs+1 .. xs+3 are walked serially so that the supersteps start 4-aligned.
-    for (uint32_t o = lane * 4; o < head; o += 256)
-      *reinterpret_cast<uint32_t*>(ring + rix(o)) = *reinterpret_cast<const uint32_t*>(hp + o);
-    wave_lds_sync();
-    {
-      int w = ring[rix(xs)];
-      for (uint32_t i = xs + 1; i < head; i++) {
-        const int x = (ring[rix(i)] + cg_pred(ring[rix(i - xs)], w, ring[rix(i - xs - 1)])) & 0xff;
-        ring[rix(i)] = (uint8_t)x;  // every lane writes the same value
-        w = x;
-      }
-    }
-    wave_lds_sync();
-    for (uint32_t o = lane * 4; o < head; o += 256)
-      emit4(o, *reinterpret_cast<const uint32_t*>(ring + rix(o)),
-            *reinterpret_cast<const uint32_t*>(lsrc + o) & lmask,
-            *reinterpret_cast<const uint32_t*>(dhsrc + o) & dmask,
-            *reinterpret_cast<const uint32_t*>(dlsrc + o) & dmask);
-    w_prev = (uint32_t)ring[rix(head - 1)] << 8;  // wave-uniform: final x[s-1] << 8
-  } else {  // residuals of block 0
-    auto first = [&](auto k0, auto k1) {
-      if (IP) {  // blocks 0 and 1 (2 M <= nslots: slot t)
-        for (uint32_t t = 0; t < 2u * M && t < nsteps; t++) dma_r_ip(t, t, k0, k1);
-      } else {
-        for (uint32_t t = 0; t < (uint32_t)M && t < nsteps; t++) dma_r(t, k0, k1);
-      }
-    };
-    if (role == 1) first(IC0{}, ICA{});
-    else first(ICA{}, ICK{});
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  lds_barrier();
-
-  // One phase of an i/o wave, for its own k-groups: the residuals of block b + 1 first (the chain
-  // wave needs them behind the next barrier: they get the whole phase to land), then the output
-  // of block b - 1 (ring + the plane bytes staged a phase ago -> delta^-1 + recombine ->
-  // stores), then the plane bytes of block b into the slots just read -- all loads by LDS-DMA.
-  // vmcnt retires in issue order, so the counted wait in front of the barrier retires the
-  // residual loads and the stores and leaves the plane loads, issued last, in flight: they are
-  // used a whole phase later, behind the wait at the top.
-  // The LDS reads of the output are inline assembly: in front of a compiler-visible LDS access
-  // that follows LDS-DMA the backend inserts s_waitcnt vmcnt(0) (the DMA might write the same
-  // bytes), which would drain the residual loads just issued.  The reads of a superstep and
-  // their wait are ONE statement, so no value exists outside it before it has landed.
-  const uint32_t ring_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(ring));
-  const uint32_t lbuf_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lbuf));
-  auto io_phase = [&](uint32_t b, auto k0, auto k1) {
-    constexpr int NK = decltype(k1)::value - decltype(k0)::value;
-    if constexpr (NK > 0) {
-#ifdef FPV_EXP_WAITS
-      const uint64_t exp_a = clock64();
-#endif
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the planes of block b - 1 have landed
-#ifdef FPV_EXP_WAITS
-      exp_top += clock64() - exp_a;
-#endif
-#pragma unroll
-      for (int q = 0; q < M; q++) {
-        const uint32_t t = (b + 1) * M + q;
-        if (t < nsteps) dma_r(t, k0, k1);
-      }
-      bool all = true;
-#pragma unroll
-      for (int q = 0; q < M; q++) {
-        const uint32_t t = (b - 1) * M + q;
-        if (b >= 1 && t < nsteps) {
-          const uint32_t s0 = head + t * S;
-          const uint32_t base = lbuf_lds + q * 3 * S;
-          const bool full = s0 + S <= npix;  // every superstep but the last one
-          uint32_t h4[NK], l4[NK], dh4[NK], dl4[NK], ra[NK], pa[NK];
-#pragma unroll
-          for (int k = 0; k < NK; k++) {
-            const uint32_t o = ((k0 + k) * 64 + lane) * 4;
-            ra[k] = ring_lds + rix(s0 + o);
-            pa[k] = base + o;
-          }
-          // reads and their wait in ONE statement: no value exists outside it before it has landed
-#define FPV_RD4(H, L, DH, DL, RA, PA) \
-  "ds_read_b32 " H ", " RA "\n\tds_read_b32 " L ", " PA "\n\tds_read_b32 " DH ", " PA " offset:%c[s1]\n\tds_read_b32 " DL ", " PA " offset:%c[s2]\n\t"
-          static_assert(2 * S < 65536, "plane offsets are DS immediates");
-          if constexpr (NK == 1) {
-            asm volatile(FPV_RD4("%0", "%1", "%2", "%3", "%4", "%5") "s_waitcnt lgkmcnt(0)"
-                         : "=&v"(h4[0]), "=&v"(l4[0]), "=&v"(dh4[0]), "=&v"(dl4[0])
-                         : "v"(ra[0]), "v"(pa[0]), [s1] "n"(S), [s2] "n"(2 * S) : "memory");
-          } else if constexpr (NK == 2) {
-            asm volatile(FPV_RD4("%0", "%1", "%2", "%3", "%8", "%9") FPV_RD4("%4", "%5", "%6", "%7", "%10", "%11") "s_waitcnt lgkmcnt(0)"
-                         : "=&v"(h4[0]), "=&v"(l4[0]), "=&v"(dh4[0]), "=&v"(dl4[0]), "=&v"(h4[1]), "=&v"(l4[1]), "=&v"(dh4[1]), "=&v"(dl4[1])
-                         : "v"(ra[0]), "v"(pa[0]), "v"(ra[1]), "v"(pa[1]), [s1] "n"(S), [s2] "n"(2 * S) : "memory");
-          } else {
-            static_assert(NK == 3, "an i/o wave owns one to three k-groups");
-            asm volatile(FPV_RD4("%0", "%1", "%2", "%3", "%12", "%13") FPV_RD4("%4", "%5", "%6", "%7", "%14", "%15")
-                         FPV_RD4("%8", "%9", "%10", "%11", "%16", "%17") "s_waitcnt lgkmcnt(0)"
-                         : "=&v"(h4[0]), "=&v"(l4[0]), "=&v"(dh4[0]), "=&v"(dl4[0]), "=&v"(h4[1]), "=&v"(l4[1]), "=&v"(dh4[1]), "=&v"(dl4[1]),
-                           "=&v"(h4[2]), "=&v"(l4[2]), "=&v"(dh4[2]), "=&v"(dl4[2])
-                         : "v"(ra[0]), "v"(pa[0]), "v"(ra[1]), "v"(pa[1]), "v"(ra[2]), "v"(pa[2]), [s1] "n"(S), [s2] "n"(2 * S) : "memory");
-          }
-#undef FPV_RD4
-#pragma unroll
-          for (int k = 0; k < NK; k++) {
-            const uint32_t px = s0 + ((k0 + k) * 64 + lane) * 4;
-            if (full || px < npix) emit4(px, h4[k], l4[k] & lmask, dh4[k] & dmask, dl4[k] & dmask);
-          }
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < M; q++) {  // (the reads above have returned: the plane slots may be refilled)
-        const uint32_t t = b * M + q;
-        if (t < nsteps) {
-          uint8_t* base = lbuf + q * 3 * S;
-#pragma unroll
-          for (int k = k0; k < k1; k++) {
-            const uint32_t ic = min(head + t * S + (k * 64 + lane) * 4, last4);
-            dma4(lsrc + ic, base + k * 256);
-#ifdef FPV_EXP_DELTA_WINDOW  // timing experiment only (wrong pixels): the delta planes' bytes from a 4 KB window that stays in the L1
-            dma4(dhsrc + (ic & 4095u), base + S + k * 256);
-            dma4(dlsrc + (ic & 4095u), base + 2 * S + k * 256);
-#else
-            dma4(dhsrc + ic, base + S + k * 256);
-            dma4(dlsrc + ic, base + 2 * S + k * 256);
-#endif
-          }
-        } else {
-          all = false;
-        }
-      }
-      // (Round 4 tried to leave this phase's stores in flight across the barrier as well -- a wait for
-      // 4 * M * NK instead of 3 * M * NK operations: only the residual loads, the oldest, have to be
-      // back --: +0.5 ... +0.9 % at 1000 frames.  The stores' acknowledgements are not what the i/o
-      // waves wait for.)
-#ifdef FPV_EXP_WAITS
-      const uint64_t exp_c = clock64();
-#endif
-      if (all) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * M * NK) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifdef FPV_EXP_WAITS
-      exp_pre += clock64() - exp_c;
-#endif
-    }
-  };
-  // IP: one phase of an i/o wave.  (1) the residuals of block b + 2 into the ring; (2) the low plane of block b into the low
-  // buffer of its parity (emitted a phase later); (3) a counted wait that leaves those two groups in flight: everything older
-  // is back -- the residuals of block b + 1 (the chain wave's next block), the low plane and the delta planes' bytes of block
-  // b - 1; (4) the output of block b - 1; (5) the delta planes' bytes of block b into the slots just read.  Nothing is waited
-  // for in front of the barrier.  The two i/o waves split the work by SUPERSTEP (wave 1 the even ones of a block, wave 2 the
-  // odd ones: a wave emits what it has loaded itself, so its own counted wait is all the ordering its plane bytes need), and a
-  // superstep's bytes come in pieces of 1 KiB (global_load_lds_dwordx4: a quarter of the DMA instructions, each of which costs
-  // the issuing wave a hundred clocks or more -- with dword pieces the i/o waves needed the whole phase just to issue theirs).
-  // S bytes of `plane` that belong to superstep t -> dst (wave-uniform).  Returns false when the superstep is the frame's last and
-  // short (dword pieces with clamped addresses then: a 16-byte piece could reach past the end of the plane)
-  auto dma_span = [&](const uint8_t* plane, uint32_t t, uint8_t* dst) -> bool {
-    constexpr int P16 = S / 1024, P4 = (S % 1024) / 256;
-    const uint32_t s0 = head + t * S;
-    if (s0 + S <= npix) {
-#pragma unroll
-      for (int p = 0; p < P16; p++) dma16(plane + s0 + p * 1024 + lane * 16, dst + p * 1024);
-#pragma unroll
-      for (int p = 0; p < P4; p++) dma4(plane + s0 + P16 * 1024 + p * 256 + lane * 4, dst + P16 * 1024 + p * 256);
-      return true;
-    }
-#pragma unroll
-    for (int k = 0; k < K4; k++) dma4(plane + min(s0 + (k * 64 + lane) * 4, last4), dst + k * 256);
-    return false;
-  };
-  uint32_t io_rslot = (2u * M) % nslots, io_eslot = 0;  // ring slots of the first supersteps of blocks b + 2 and b - 1 (counters, as the chain wave's)
-  auto slot_at = [&](uint32_t s0, int q) { const uint32_t v = s0 + q; return v >= nslots ? v - nslots : v; };
-  auto io_phase_ip = [&](uint32_t b, auto wp) {
-    constexpr int WP = decltype(wp)::value;          // this wave's supersteps of a block: q = WP, WP + 2, ..
-    constexpr int NQ = (M - WP + 1) / 2;
-    constexpr int NP = (int)(S / 1024 + (S % 1024) / 256);  // DMA pieces per superstep and plane
-    if constexpr (NQ > 0) {
-      bool all = true;
-      const uint32_t par = b & 1u;
-#pragma unroll
-      for (int q = WP; q < M; q += 2) {
-        const uint32_t t = (b + 2) * M + q;
-        if (t < nsteps) all = dma_span(hp, t, ring + slot_at(io_rslot, q) * S) && all;
-        else all = false;
-      }
-      const uint32_t eslot = io_eslot;
-      io_rslot = slot_at(io_rslot, M);
-      if (b >= 1) io_eslot = slot_at(io_eslot, M);
-#pragma unroll
-      for (int q = WP; q < M; q += 2) {
-        const uint32_t t = b * M + q;
-        if (t < nsteps) all = dma_span(lsrc, t, lbuf + q * 4 * S + par * S) && all;
-        else all = false;
-      }
-#ifdef FPV_EXP_WAITS
-      const uint64_t exp_a = clock64();
-#endif
-      if (all) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NQ * NP) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifdef FPV_EXP_WAITS
-      exp_top += clock64() - exp_a;
-#endif
-#pragma unroll
-      for (int q = WP; q < M; q += 2) {
-        const uint32_t t = (b - 1) * M + q;
-        if (b >= 1 && t < nsteps) {
-          const uint32_t s0 = head + t * S;
-          const uint32_t rbase = ring_lds + slot_at(eslot, q) * S;
-          const uint32_t base = lbuf_lds + q * 4 * S;
-          const bool full = s0 + S <= npix;  // every superstep but the last one
-#pragma unroll
-          for (int k0 = 0; k0 < K4; k0 += 2) {  // two k-groups (64 lanes x 4 bytes each) per statement
-            const int nk = k0 + 1 < K4 ? 2 : 1;
-            uint32_t h4[2], l4[2], dh4[2], dl4[2], ra[2], pa[2], la[2];
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-              const uint32_t o = ((k0 + (k < nk ? k : 0)) * 64 + lane) * 4;
-              ra[k] = rbase + o;
-              pa[k] = base + o;
-              la[k] = base + (par ^ 1u) * S + o;  // block b - 1's parity
-            }
-            // reads and their wait in ONE statement: no value exists outside it before it has landed
-            // (8 pixels per lane -- 64-bit reads, 16-byte stores -- measured no faster: profiles/r05_inverse_ab.log)
-#define FPV_RD4I(H, L, DH, DL, RA, LA, PA) \
-  "ds_read_b32 " H ", " RA "\n\tds_read_b32 " L ", " LA "\n\tds_read_b32 " DH ", " PA " offset:%c[s2]\n\tds_read_b32 " DL ", " PA " offset:%c[s3]\n\t"
-            static_assert(3 * S < 65536, "plane offsets are DS immediates");
-            asm volatile(FPV_RD4I("%0", "%1", "%2", "%3", "%8", "%9", "%10") FPV_RD4I("%4", "%5", "%6", "%7", "%11", "%12", "%13") "s_waitcnt lgkmcnt(0)"
-                         : "=&v"(h4[0]), "=&v"(l4[0]), "=&v"(dh4[0]), "=&v"(dl4[0]), "=&v"(h4[1]), "=&v"(l4[1]), "=&v"(dh4[1]), "=&v"(dl4[1])
-                         : "v"(ra[0]), "v"(la[0]), "v"(pa[0]), "v"(ra[1]), "v"(la[1]), "v"(pa[1]), [s2] "n"(2 * S), [s3] "n"(3 * S) : "memory");
-#undef FPV_RD4I
-#pragma unroll
-            for (int k = 0; k < nk; k++) {
-              const uint32_t px = s0 + ((k0 + k) * 64 + lane) * 4;
-              if (full || px < npix) emit4(px, h4[k], l4[k] & lmask, dh4[k] & dmask, dl4[k] & dmask);
-            }
-          }
-        }
-      }
-#pragma unroll
-      for (int q = WP; q < M; q += 2) {  // (the reads above have returned: the delta slots may be refilled)
-        const uint32_t t = b * M + q;
-        if (t < nsteps) {
-          dma_span(dhsrc, t, lbuf + q * 4 * S + 2 * S);
-          dma_span(dlsrc, t, lbuf + q * 4 * S + 3 * S);
-        }
-      }
-    }
-  };
-  // Each role runs its own loop over the blocks; every wave passes the same nblocks + 1 barriers.
-  auto sync = [&] {
-#ifdef FPV_EXP_WAITS
-    const uint64_t exp_b = clock64();
-#endif
-    lds_barrier();
-#ifdef FPV_EXP_WAITS
-    exp_bar += clock64() - exp_b;
-#endif
-  };
-  if (role == 0) {
-    uint32_t cslot = 0;  // IP: the ring slot of superstep t
-    uint32_t res_in = 0;  // RES: the (verified) incoming pixel of this lane's segment in the superstep before = the pixel above-left of its next segment
-    // One superstep of the chain wave.  N: the bytes above the lane's segment as v << 8 operands -- loaded from the ring, or (RES,
-    // every superstep but the first) already there: what the superstep before left in its X; X: receives the segment's pixels.
-    auto chain_step = [&](uint32_t t, uint32_t (&N)[K], uint32_t (&X)[K], bool north_in_regs) {
-        const uint32_t s0 = head + t * S, start = s0 + lane * K;
-        const bool active = start < npix;
-#if FPV_INV_LEAN
-        uint32_t D[K], RL[K4], RH[K4];  // residuals stay packed: see inv_px4w
-#else
-        uint32_t D[K], R[K];
-#endif
-        uint32_t guess;
-        // IP: ring offsets of this lane's segment (os), of the bytes above it (on: xs % K == 0, so they do not straddle the
-        // ring's end) and of the dword in front of those (onb)
-        uint32_t os = 0, on = 0, onb = 0;
-        if (IP) {
-          os = cslot * S + lane * K;
-          cslot = cslot + 1 == nslots ? 0 : cslot + 1;  // superstep t lies at slot t mod nslots (a counter: nslots is no power of two)
-          on = os >= xs ? os - xs : os + ring_bytes - xs;
-          onb = on >= 4 ? on - 4 : ring_bytes - 4;
-        }
-        if (RES && north_in_regs) {
-          // The row is one superstep long: the bytes above this lane's segment are the pixels the same lane made a superstep ago
-          // (N holds them as it stands), the one above-left of its first pixel is that superstep's verified input.  Only the
-          // residuals come from LDS.
-          uint32_t rq[K4];
-          if constexpr (K4 == 4) {
-            const uint4 r = *reinterpret_cast<const uint4*>(ring + os);
-            rq[0] = r.x; rq[1] = r.y; rq[2] = r.z; rq[3] = r.w;
-          } else {
-#pragma unroll
-            for (int q = 0; q < K4; q++) rq[q] = *reinterpret_cast<const uint32_t*>(ring + os + 4 * q);
-          }
-          guess = res_in;
-          D[0] = N[0] - res_in;
-#pragma unroll
-          for (int k = 1; k < K; k++) D[k] = N[k] - N[k - 1];
-#pragma unroll
-          for (int q = 0; q < K4; q++) {
-#if FPV_INV_LEAN
-            RL[q] = r_lo(rq[q]);
-            RH[q] = r_hi(rq[q]);
-#else
-#pragma unroll
-            for (int b = 0; b < 4; b++) R[4 * q + b] = __builtin_amdgcn_perm(0, rq[q], 0x0c0c000cu | ((uint32_t)b << 8));
-#endif
-          }
-        } else {
-          const uint32_t nb = start - xs - 4;  // dword holding the north-west of the first pixel
-          uint32_t nd[K4 + 1], rq[K4];
-          if constexpr (IP) {
-            nd[0] = *reinterpret_cast<const uint32_t*>(ring + onb);
-            if constexpr (K4 == 4) {  // 16-byte accesses: os, xs and the ring's length are multiples of 16
-              const uint4 a = *reinterpret_cast<const uint4*>(ring + on);
-              nd[1] = a.x; nd[2] = a.y; nd[3] = a.z; nd[4] = a.w;
-              const uint4 r = *reinterpret_cast<const uint4*>(ring + os);
-              rq[0] = r.x; rq[1] = r.y; rq[2] = r.z; rq[3] = r.w;
-            } else {
-#pragma unroll
-              for (int q = 0; q < K4; q++) nd[q + 1] = *reinterpret_cast<const uint32_t*>(ring + on + 4 * q);
-#pragma unroll
-              for (int q = 0; q < K4; q++) rq[q] = *reinterpret_cast<const uint32_t*>(ring + os + 4 * q);
-            }
-          } else if constexpr (K4 == 4) {
-            // 16 bytes per lane: dword accesses at a lane stride of 16 bytes are four-way bank conflicts
-            // (odd K4: conflict-free), one 128-bit access per lane is not.  The ring is laid out so
-            // that a lane's four north dwords, and (xs % 16 == 0) the four it writes, are aligned.
-            nd[0] = *reinterpret_cast<const uint32_t*>(ring + rix(nb));
-            const uint4 a = *reinterpret_cast<const uint4*>(ring + rix(nb + 4));  // rix(nb + 4) = (t * S + lane * 16) & m
-            nd[1] = a.x; nd[2] = a.y; nd[3] = a.z; nd[4] = a.w;
-            const uint4 r = *reinterpret_cast<const uint4*>(rbuf + (t & (2 * M - 1)) * S + lane * 16);
-            rq[0] = r.x; rq[1] = r.y; rq[2] = r.z; rq[3] = r.w;
-          } else {
-#pragma unroll
-            for (int q = 0; q <= K4; q++) nd[q] = *reinterpret_cast<const uint32_t*>(ring + rix(nb + 4 * q));
-#pragma unroll
-            for (int q = 0; q < K4; q++) rq[q] = *reinterpret_cast<const uint32_t*>(rbuf + (t & (2 * M - 1)) * S + lane * K + 4 * q);
-          }
-          uint32_t prev = __builtin_amdgcn_perm(0, nd[0], 0x0c0c030cu);
-          guess = prev;  // x[start - 1 - xs] << 8
-#pragma unroll
-          for (int q = 0; q < K4; q++) {
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-              const uint32_t sel = 0x0c0c000cu | ((uint32_t)b << 8);
-              const uint32_t n = __builtin_amdgcn_perm(0, nd[q + 1], sel);
-              N[4 * q + b] = n;
-              D[4 * q + b] = n - prev;
-#if !FPV_INV_LEAN
-              R[4 * q + b] = __builtin_amdgcn_perm(0, rq[q], sel);
-#endif
-              prev = n;
-            }
-#if FPV_INV_LEAN
-            RL[q] = r_lo(rq[q]);
-            RH[q] = r_hi(rq[q]);
-#endif
-          }
-        }
-        uint32_t in = lane == 0 ? w_prev : guess;
-        bool run = true;
-        const uint32_t npass0 = npass;
-        bool settled = false;
-#if FPV_INV_LEAN
-        const uint64_t active_mask = __builtin_amdgcn_ballot_w64(active);
-        for (uint32_t round = 0; round < kScanAfter; round++) {  // the common case ends in here
-          uint32_t w = in, pred;  // every lane, every pass (see inv_px4w)
-#pragma unroll
-          for (int k = 0; k < K; k += 4) w = inv_px4w(N + k, w, D + k, RL[k / 4], RH[k / 4], X + k);
-          npass++;
-#ifdef FPV_EXP_ONEPASS  // timing experiment only (wrong pixels): how much of the time is the passes?
-          settled = true; break;
-#endif
-          if (!chain_check(X[K - 1], in, w_prev, lane == 0, active_mask, &pred)) { settled = true; break; }
-          in = pred;
-        }
-#else
-        for (uint32_t round = 0; round < kScanAfter; round++) {  // the common case ends in here
-          if (run) {
-            uint32_t w = in;
-#pragma unroll
-            for (int k = 0; k < K; k += 4) w = inv_px4(N + k, w, D + k, R + k, X + k);
-          }
-          npass++;
-          uint32_t pred = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)X[K - 1], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-          if (lane == 0) pred = w_prev;
-          run = active && pred != in;
-#ifdef FPV_EXP_ONEPASS  // timing experiment only (wrong pixels): how much of the time is the passes?
-          settled = true; break;
-#endif
-          if (!__builtin_amdgcn_ballot_w64(run)) { settled = true; break; }
-          in = pred;
-        }
-#endif
-        if (__builtin_expect(!settled, 0)) {  // long correction chain: see k_inverse_spec
-          uint32_t all, ord = 0, sum = 0;
-          asm volatile("v_mov_b32 %0, -1" : "=v"(all));
-#if FPV_INV_LEAN
-          uint32_t R[K];
-#pragma unroll
-          for (int k = 0; k < K; k += 4) {
-            R[k] = RL[k / 4] & 0xffffu; R[k + 1] = RH[k / 4] & 0xffffu; R[k + 2] = RL[k / 4] >> 16; R[k + 3] = RH[k / 4] >> 16;
-          }
-          run = true;
-#endif
-#pragma unroll
-          for (int k = 0; k < K; k++) { ord = max(ord, D[k] & all); sum += R[k] & all; }
-          const bool is_shift = ord == 0 && lane != 0;
-          const uint32_t ssum = sum & 0xffffu;
-          for (;;) {
-            if (run) {
-              uint32_t w = in;
-#pragma unroll
-              for (int k = 0; k < K; k += 4) w = inv_px4(N + k, w, D + k, R + k, X + k);
-            }
-            npass++;
-            uint32_t pred = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)X[K - 1], 0x138, 0xf, 0xf, false);
-            if (lane == 0) pred = w_prev;
-            const bool bad = active && pred != in;
-            if (!__builtin_amdgcn_ballot_w64(bad)) break;
-            uint32_t next_in = pred;
-            if (npass - npass0 < kScanUntil) {
-              uint32_t isc = is_shift ? 0u : 1u, v = is_shift ? ssum : X[K - 1];
-#pragma unroll
-              for (int dlt = 1; dlt < 64; dlt <<= 1) {
-                const uint32_t isc_l = __shfl_up(isc, dlt, 64), v_l = __shfl_up(v, dlt, 64);
-                if (lane >= (uint32_t)dlt && !isc) {
-                  v = (v + v_l) & 0xffffu;
-                  isc = isc_l;
-                }
-              }
-              next_in = __shfl_up(v, 1, 64);
-              if (lane == 0) next_in = w_prev;
-            }
-            run = active && next_in != in;
-            in = next_in;
-          }
-        }
-        maxpass = max(maxpass, npass - npass0);
-        w_prev = (uint32_t)__builtin_amdgcn_readlane((int)X[K - 1], 63);
-        uint32_t packed[K4];
-#pragma unroll
-        for (int q = 0; q < K4; q++)
-          packed[q] = __builtin_amdgcn_perm(X[4 * q + 1], X[4 * q], 0x0c0c0501u) |
-                      __builtin_amdgcn_perm(X[4 * q + 3], X[4 * q + 2], 0x05010c0cu);
-        if constexpr (IP) {  // over the residuals they were made of
-          if constexpr (K4 == 4) {
-            *reinterpret_cast<uint4*>(ring + os) = make_uint4(packed[0], packed[1], packed[2], packed[K4 - 1]);
-          } else {
-#pragma unroll
-            for (int q = 0; q < K4; q++) *reinterpret_cast<uint32_t*>(ring + os + 4 * q) = packed[q];
-          }
-        } else if (K4 == 4 && (xs & 15) == 0) {  // rix(start) = (xs + t * S + lane * 16) & m: 16-byte aligned
-          *reinterpret_cast<uint4*>(ring + rix(start)) = make_uint4(packed[0], packed[1], packed[2], packed[K4 - 1]);
-        } else {
-#pragma unroll
-          for (int q = 0; q < K4; q++) *reinterpret_cast<uint32_t*>(ring + rix(start + 4 * q)) = packed[q];
-        }
-        res_in = in;
-    };
-    if constexpr (RES) {
-      // Two register sets taking turns (M is even: even supersteps read P and write Q, odd ones the other way round): the
-      // pixels of one superstep ARE the north operands of the next, without a copy.
-      uint32_t P[K], Q[K];
-      for (uint32_t b = 0; b <= nblocks; b++) {
-#pragma unroll 1
-        for (uint32_t t = b * M; t < (b + 1) * M && t < nsteps; t += 2) {
-          chain_step(t, P, Q, t > 0);
-          if (t + 1 < nsteps) chain_step(t + 1, Q, P, true);
-        }
-        sync();
-      }
-    } else {
-      for (uint32_t b = 0; b <= nblocks; b++) {
-#pragma unroll 1
-        for (uint32_t t = b * M; t < (b + 1) * M && t < nsteps; t++) {
-          uint32_t N[K], X[K];
-          chain_step(t, N, X, false);
-        }
-        sync();
-      }
-    }
-  } else if (role == 1) {
-    for (uint32_t b = 0; b <= nblocks; b++) {
-      if constexpr (IP) io_phase_ip(b, IC0{});
-      else io_phase(b, IC0{}, ICA{});
-      sync();
-    }
-  } else {
-    for (uint32_t b = 0; b <= nblocks; b++) {
-      if constexpr (IP) io_phase_ip(b, std::integral_constant<int, 1>{});
-      else io_phase(b, ICA{}, ICK{});
-      sync();
-    }
-  }
-  if (role == 0 && lane == 0 && claimed_simd < 4) atomicAnd(&g_chain_simd_mask[cu_index], ~(1u << claimed_simd));
-#ifdef FPV_EXP_WAITS
-  if (pass_count && lane == 0) {
-    const uint32_t tot = (uint32_t)((clock64() - exp_t0) >> 4);
-    if (role == 0) { atomicAdd(&pass_count[4], (uint32_t)(exp_bar >> 4)); atomicAdd(&pass_count[5], tot); }
-    if (role == 1) {
-      atomicAdd(&pass_count[8], (uint32_t)(exp_bar >> 4)); atomicAdd(&pass_count[7], tot);
-      atomicAdd(&pass_count[9], (uint32_t)(exp_top >> 4)); atomicAdd(&pass_count[10], (uint32_t)(exp_pre >> 4));
-    }
-  }
-#endif
-  if (pass_count && role == 0 && lane == 0) {  // diagnostics: supersteps and passes (bench / tests)
-    atomicAdd(&pass_count[0], nsteps);
-    atomicAdd(&pass_count[1], npass);
-    atomicMax(&pass_count[2], npass);
-    atomicMax(&pass_count[3], maxpass);
-  }
-#ifdef FPV_EXP_HWID  // experiment (destroys the first four pixels): where the chain wave ran and for how long
-  if (role == 0 && lane == 0) {
-    uint32_t hw, xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    uint32_t* o = reinterpret_cast<uint32_t*>(outp);
-    o[0] = (xcc & 0xf) << 16 | (hw & 0xffff);
-    o[1] = (uint32_t)((clock64() - exp_hw_t0) >> 4);
-  }
-#endif
-}
+#include "fpv_inverse.inc"
 
 }  // namespace
 

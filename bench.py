@@ -504,6 +504,14 @@ def main():
                     sub[str(m)] = {"ms_per_batch": round(ms2, 4), "us_per_frame": round(1e3 * ms2 / m, 2),
                                    "frac": round(m * 4 * NPIX / ms2 / 1e6 / HBM_PEAK_GBPS, 4)}
             inv["smaller_batches"] = sub
+            # the inverse is a serial chain of npix steps per frame (cc:326-333); what ONE frame's chain costs
+            # where nothing else bounds it (the smallest batch: every frame has a CU to itself)
+            m0 = min(int(k) for k in sub)
+            inv["chain"] = {"frames": m0, "ns_per_pixel_of_one_frame": round(1e6 * sub[str(m0)]["ms_per_batch"] / NPIX, 4),
+                            "kernel": pred.inverse_kernel_name(m0),
+                            "note": "batch time / pixels per frame at the smallest batch: the latency of one frame's speculative segmented chain "
+                                    "(64 segments of a row in parallel, passes_per_superstep passes of 3 dependent instructions per pixel); the "
+                                    "reference walks the same chain pixel by pixel (cc:326-333: 5.7 ms per frame on the survey's host = 5.6 ns per pixel)"}
             inv["product_decode_batch"] = {
                 "frames": 32, "env": "FPV_DECODE_BATCH",
                 "note": "RandomAccessDecoder::DecodeFrames / StreamingDecoder hand the GPU batches of 32 frames (two slots, 4 bytes of pinned "

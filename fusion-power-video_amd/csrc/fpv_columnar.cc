@@ -318,6 +318,11 @@ struct ColumnarBatchEncoder::Impl {
         // two workers overlap the Brotli of one batch with the column copies and the
         // processor call of the one before; batches still leave in submission order
         cv.wait(l, [&] { return next_emit == p.seq; });
+        // Every batch in front of this one has now been stored or has latched its failure: one that failed while this one
+        // was being compressed (the other worker's) makes this one a batch BEHIND the failure -- dropped, so that what the
+        // processor has seen stays a clean prefix (under load the other worker's failing wait can return after this worker's
+        // successful one).
+        if (ok && latch.failed()) ok = false;
         if (ok) latest_stored = batch->LatestTimestamp();
       }
       if (ok) processor(batch);  // one batch at a time, in order

@@ -265,7 +265,9 @@ def test_gpu_failure_is_latched_not_fatal(tmp_path):
     import sys
     if not os.path.exists(SHIM):
         pytest.skip("tests/shim not built")
-    res, err = _run_pipe(tmp_path, {"FPV_SHIM_DEVICES": "2", "FPV_SHIM_FAIL_WAIT": "6", "FPV_BATCH": "4"})
+    # (the 10th wait of the process: two warm-ups, the delta frame, then batches -- a device may run up to three batches ahead
+    # of the other, so with a smaller number a loaded machine can make the failing wait batch 0's, an EMPTY prefix)
+    res, err = _run_pipe(tmp_path, {"FPV_SHIM_DEVICES": "2", "FPV_SHIM_FAIL_WAIT": "10", "FPV_BATCH": "4"})
     ids = [int(v) for v in res["IDS"].split()]
     assert ids[0] == 1000000 and 2000000 not in ids and 3000000 not in ids   # header, but no index
     frames = ids[1:]

@@ -281,6 +281,33 @@ def test_gpu_failure_is_latched_not_fatal(tmp_path):
     assert out.returncode != 0 and "fatal" in out.stderr
 
 
+def test_gpu_failure_at_random_points_leaves_a_clean_prefix(tmp_path):
+    """The same failure injected at a random wait of sessions of random shape (devices, batch size, worker threads, frames): whatever
+    the point -- a warm-up, the delta frame in Init (then not even the header comes out), any batch of any device -- the callbacks
+    have seen the header and frames 1 .. k in order and nothing else, k < n and no index when the failure hit, everything and the
+    index when the session ended before the injected wait was reached."""
+    import random
+    if not os.path.exists(SHIM):
+        pytest.skip("tests/shim not built")
+    rnd = random.Random(5)
+    hit = clean = 0
+    for _ in range(10):
+        devs, fw = rnd.choice([1, 2, 3, 8]), rnd.randint(4, 40)
+        batch, th, n = rnd.choice([1, 3, 4, 8]), rnd.choice([1, 2, 4, 8]), rnd.choice([40, 97])
+        res, err = _run_pipe(tmp_path, {"FPV_SHIM_DEVICES": str(devs), "FPV_SHIM_FAIL_WAIT": str(fw), "FPV_BATCH": str(batch)}, nframes=n, threads=th)
+        ids = [int(v) for v in res["IDS"].split()]
+        frames = [i for i in ids if i < 1000000]
+        what = dict(devs=devs, fail_wait=fw, batch=batch, threads=th, frames=n)
+        assert frames == list(range(1, len(frames) + 1)), what
+        if "injected failure" in res["ERR"]:
+            hit += 1
+            assert 2000000 not in ids and len(frames) < n and (not ids or ids[0] == 1000000), what
+        else:
+            clean += 1
+            assert ids[0] == 1000000 and ids[-1] == 2000000 and len(frames) == n, what
+    assert hit >= 3, (hit, clean)
+
+
 _WARM_SCRIPT = r'''
 import sys, os, importlib, hashlib, ctypes
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))

@@ -148,6 +148,39 @@ static void Columnar() {
            got_rows, (long long)last);
     EXPECT(refused + threw > 0, "no PushFrame reported the failure");
   }
+  // the same at every early wait and two batch sizes: whatever batch the failure hits (on a loaded machine the wait of batch k + 1
+  // can return before the failing wait of batch k), the processor has seen whole batches 0 .. j - 1 and nothing behind them
+  for (int fw = 2; fw <= 9; fw++)
+    for (int per_batch : {3, 5}) {
+      size_t got_rows = 0;
+      int64_t max_ts = -1;
+      bool gap = false;
+      char v[16];
+      snprintf(v, sizeof v, "%d", fw);
+      setenv("FPV_SHIM_FAIL_WAIT", v, 1);
+      {
+        ColumnarBatchEncoder enc(xs, ys, 4, false, [&](BatchPtr b) {
+          std::lock_guard<std::mutex> l(m);
+          if (!b) return;
+          if (b->LatestTimestamp() != (int64_t)(1000 + got_rows + b->length()) - 1) gap = true;  // not the next rows in order
+          got_rows += b->length();
+          max_ts = b->LatestTimestamp();
+        }, per_batch);
+        for (size_t k = 0; k < n; k++) {
+          std::future<void*> f = enc.PushFrame(1000 + k, frames[k].data(), nullptr);
+          if (!f.valid()) continue;
+          try { f.get(); } catch (const std::exception&) {}
+        }
+        const int64_t last = enc.Close().get();
+        unsetenv("FPV_SHIM_FAIL_WAIT");
+        const bool failed = !enc.LastError().empty();
+        EXPECT(!gap, "fail_wait %d, %d per batch: the processor saw a batch behind a gap", fw, per_batch);
+        EXPECT(failed ? got_rows < n && got_rows % per_batch == 0 : got_rows == n, "fail_wait %d, %d per batch: %zu rows stored (failed %d)", fw,
+               per_batch, got_rows, (int)failed);
+        EXPECT(got_rows == 0 || last == max_ts, "fail_wait %d, %d per batch: Close says %lld, the last batch stored %lld", fw, per_batch,
+               (long long)last, (long long)max_ts);
+      }
+    }
   // a failing submit surfaces in the very PushFrame that closes the batch
   {
     setenv("FPV_SHIM_FAIL_SUBMIT", "2", 1);

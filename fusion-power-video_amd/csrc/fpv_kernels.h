@@ -65,6 +65,7 @@ struct FwdWorkspace {
   uint8_t* trec;         // tile pass: [nframes][tiles] per-tile records (partial heuristic histograms, low-byte word)
   uint8_t* pvraw;        // tile pass: [nframes][npv] raw preview
   uint32_t* spec_pos;    // tile pass: [nframes] per-position prediction state
+  uint32_t* dpart;       // tile pass: [kDecideSlots][kDecidePartWords] k_tile_decide's partial sums when several workgroups share a frame
   uint32_t nframes;      // capacity
   size_t zero_bytes;     // leading bytes cleared once at creation (counters, anylow, frame_done, bdone)
   uint32_t seq;          // batches launched so far (selects the counter block); host side

@@ -1328,6 +1328,25 @@ static uint32_t device_cus() {
   return (uint32_t)cus[dev];
 }
 
+// Workgroups per frame of k_tile_decide: one -- unless the batch is a FEW large frames (the Encoder's batches of 4096x4096 are 8
+// frames), whose records (1.5 KB per tile, 795 KB per frame) would each go through ONE compute unit in six turns of loads while
+// the others idle: then a power of two of them, as long as every part has records for one turn of its loads and a compute
+// unit of its own (beyond that the kernel moves the same bytes in the same time: 60 frames x 8 parts 25.3 us against 24.4,
+// 113 x 4096x2160 x 4 parts 22.1 against 17.6; profiles/r05_forward_ab.log).
+// FPV_DECIDE_PARTS=n (tests, A/B runs) asks for n whatever the size; read per launch.
+static uint32_t decide_parts(uint32_t nframes, uint32_t tiles, bool big) {
+  uint32_t want = 0;
+  if (const char* e = getenv("FPV_DECIDE_PARTS")) want = (uint32_t)atoi(e);
+  uint32_t parts = 1;
+  if (want) {
+    while (parts * 2 <= want && parts < 8) parts *= 2;
+  } else if (big) {
+    while (parts < 8 && tiles / (parts * 2) >= 40 && (uint64_t)nframes * parts * 2 <= device_cus()) parts *= 2;
+  }
+  while (parts > 1 && (uint64_t)nframes * parts > kDecideSlots) parts /= 2;
+  return parts;
+}
+
 constexpr uint32_t kMaxWaveLds = 160 * 1024 - 1024;  // one wave may own (nearly) the whole LDS of a CU
 
 bool make_geom(uint32_t xs, uint32_t ys, int shift, int big_endian, Geom* g,
@@ -1536,6 +1555,7 @@ size_t fwd_workspace_bytes(const Geom& g, uint32_t max_frames) {
     b += round_up((size_t)max_frames * std::max(g.tile_tiles, g.tile8_ok ? g.tile8_tiles : 0u) * kTileRecBytes, 256);  // tile records
     b += round_up((size_t)max_frames * g.npv, 256);              // raw previews
     b += round_up(max_frames * 4, 256);                          // per-position prediction
+    b += round_up((size_t)kDecideSlots * kDecidePartWords * 4, 256);  // k_tile_decide's partial sums
   }
   b += round_up(max_frames, 256);                                // decision
   b += 2 * (size_t)round_up(max_frames * 4, 256);                // list A, list B
@@ -1555,7 +1575,7 @@ void carve_fwd_workspace(const Geom& g, uint32_t max_frames, void* base,
   p += round_up(max_frames * 4, 256);
   ws->bdone = reinterpret_cast<uint32_t*>(p);
   p += round_up((size_t)max_frames * g.redo_strips * 4, 256);
-  ws->trec = nullptr; ws->pvraw = nullptr; ws->spec_pos = nullptr;
+  ws->trec = nullptr; ws->pvraw = nullptr; ws->spec_pos = nullptr; ws->dpart = nullptr;
   ws->nframes = max_frames;
   ws->zero_bytes = (size_t)(p - static_cast<uint8_t*>(base));
   if (g.tile_ok) {
@@ -1565,6 +1585,8 @@ void carve_fwd_workspace(const Geom& g, uint32_t max_frames, void* base,
     p += round_up((size_t)max_frames * g.npv, 256);
     ws->spec_pos = reinterpret_cast<uint32_t*>(p);
     p += round_up(max_frames * 4, 256);
+    ws->dpart = reinterpret_cast<uint32_t*>(p);
+    p += round_up((size_t)kDecideSlots * kDecidePartWords * 4, 256);
   }
   ws->decision = p;
   p += round_up(max_frames, 256);
@@ -1687,6 +1709,7 @@ static hipError_t predict_impl(const Geom& g, const uint16_t* d_frames,
     a.shift = (uint32_t)g.shift; a.nframes = nframes; a.with_delta = (uint32_t)with_delta;
     a.in_pitch = a.out_pitch = g.npix;
     a.xs15 = g.xs % 15u; a.xs31 = g.xs % 31u; a.c31 = (g.xs + 1u) % 31u; a.ncg = g.ncg;
+    a.dparts = 1u;
     TilePtrs& P = L.P;
     P.frames = d_frames; P.dhigh = d_dhigh; P.dlow = d_dlow;
     P.high = d_high; P.low = d_low; P.preview = d_preview; P.flags = d_flags;
@@ -1737,6 +1760,9 @@ static hipError_t predict_impl(const Geom& g, const uint16_t* d_frames,
     P.ctr_next = ws.ctr + ((ws.seq + 1) & 1u) * 64;
     ws.seq++;
     P.decision = ws.decision; P.list_a = ws.list_a; P.list_b = ws.list_b; P.spec = reinterpret_cast<uint32_t*>(ws.spec); P.spec_pos = ws.spec_pos;
+    P.dpart = ws.dpart; P.dtick = ws.frame_done;  // (frame_done: zero since the workspace was made, unused by the tile pass otherwise)
+    const bool dbig = g.tile_tiles > 64 || g.tile_decide_big;
+    a.dparts = decide_parts(nframes, g.tile_tiles, dbig);
     const bool lowp = g.shift != 8;
     const uint32_t T = g.tile_threads, lds = g.tile_lds;
     if (ev) hipEventRecord(ev[0], s);
@@ -1748,8 +1774,8 @@ static hipError_t predict_impl(const Geom& g, const uint16_t* d_frames,
     if (lowp) k_tile<SWAP, true><<<tgrid, T, lds, s>>>(L);
     else k_tile<SWAP, false><<<tgrid, T, lds, s>>>(L);
     if (ev) hipEventRecord(ev[1], s);
-    if (g.tile_tiles > 64 || g.tile_decide_big) k_tile_decide<SWAP, true><<<nframes, 1024, 0, s>>>(L);   // many records per frame (large frames)
-    else k_tile_decide<SWAP, false><<<nframes, 256, 0, s>>>(L);
+    if (dbig) k_tile_decide<SWAP, true><<<nframes * a.dparts, 1024, 0, s>>>(L);   // many records per frame (large frames)
+    else k_tile_decide<SWAP, false><<<nframes * a.dparts, 256, 0, s>>>(L);
     if (ev) hipEventRecord(ev[2], s);
     // as many workgroups as are resident at once (two of 512 threads per CU at this kernel's registers): each takes its
     // share of the frames' previews in one turn, then its share of the redo list

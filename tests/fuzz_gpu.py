@@ -80,8 +80,10 @@ while time.time() - t0 < budget:
     os.environ["FPV_TRIO_RES"] = str(rng.choice(["1", "0"], p=[0.7, 0.3]))   # north operands in registers where the row is one superstep long (256, 1280, 1536 wide here)
     # forward path (read when the context is created): the tile pass with a random tile height where the
     # width allows it (multiples of 64), now and then the streaming kernels instead
-    for k in ("FPV_TILE_GROUPS", "FPV_FORWARD", "FPV_TILE8_GROUPS", "FPV_TILE8_ROWS", "FPV_TILE_FGROUP"):
+    for k in ("FPV_TILE_GROUPS", "FPV_FORWARD", "FPV_TILE8_GROUPS", "FPV_TILE8_ROWS", "FPV_TILE_FGROUP", "FPV_DECIDE_PARTS"):
         os.environ.pop(k, None)
+    if rng.integers(0, 3) == 0:   # k_tile_decide: several workgroups per frame, the last to arrive decides (read per launch)
+        os.environ["FPV_DECIDE_PARTS"] = str(rng.choice(["2", "4", "8"]))
     r = int(rng.integers(0, 12))
     if r == 0:
         os.environ["FPV_FORWARD"] = "stream"

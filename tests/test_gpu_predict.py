@@ -149,6 +149,41 @@ def test_large_frame_order(fpv, synth, oracle, xs, ys, n, env, want):
                 os.environ[k] = v
 
 
+@pytest.mark.parametrize("xs,ys,n,env", [
+    (320, 200, 6, {"FPV_DECIDE_PARTS": "2"}), (320, 200, 6, {"FPV_DECIDE_PARTS": "8"}), (320, 200, 6, {"FPV_DECIDE_PARTS": "4", "FPV_DECIDE_BIG": "1"}),
+    (320, 200, 6, {"FPV_DECIDE_PARTS": "8", "FPV_TILE_GROUPS": "1"}), (1280, 48, 5, {"FPV_DECIDE_PARTS": "4", "FPV_TILE_GROUPS": "1"}),
+    (4096, 1032, 3, {}), (4096, 1032, 3, {"FPV_DECIDE_PARTS": "2"}), (4096, 2064, 2, {})])
+def test_decide_in_parts(fpv, synth, oracle, xs, ys, n, env):
+    """Few large frames: several workgroups of k_tile_decide share a frame's records and the one that arrives last
+    decides (by default for more than 64 tiles per frame -- 4096 x 1032: 129 tiles, 2 parts; 4096 x 2064: 258 tiles, 4
+    parts; forced on small frames, also with more parts than tiles); twice per Predictor, so that the tickets have
+    to be back at zero for the second batch; noise (decisions flip, frames are redone) and smooth frames, with and
+    without a delta frame."""
+    import os, torch
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        fr = np.concatenate([synth.plasma_frames(n - n // 2, xs, ys, bits=12, seed=5), (synth.noise_frames(n // 2, xs, ys, seed=6) >> 4)])
+        _run_case(fpv, oracle, fr, xs, ys, 4, False, fr[0])
+        _run_case(fpv, oracle, fr[1:], xs, ys, 4, False, None)
+        p = fpv.Predictor(xs, ys, 4, False, max_batch=n)
+        p.set_delta_raw(fr[0])
+        d = torch.from_numpy(fr.reshape(n, -1).view(np.int16)).cuda()
+        first = [t.clone() for t in p.predict(d.view(torch.uint16))]
+        for order in (torch.arange(n - 1, -1, -1), torch.arange(n)):
+            got = p.predict(d[order.cuda()].contiguous().view(torch.uint16))
+            torch.cuda.synchronize()
+            for a, b in zip(first, got):
+                assert torch.equal(a[order.cuda()], b)
+        p.close()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def test_randomised_geometries_and_contents(fpv, oracle):
     """Seeded sweep: random multiple-of-4 geometries, shifts, endianness and
     content classes (noise, smooth, constant, near-constant, zero low plane,

@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from __graft_entry__ import load_package
 pkg = load_package(); synth = importlib.import_module("fpv_amd.synth")
 libs = sys.argv[1:] or [os.path.join(pkg.LIBDIR, "libfpvhip.so")]
-cases = [(4096, 4096, 60, 0, 16), (4096, 4096, 8, 0, 16), (1920, 1080, 480, 0, 16), (2048, 1536, 320, 4, 12), (1280, 800, 32, 4, 12), (1280, 800, 1000, 4, 12)]
+cases = [(4096, 4096, 60, 0, 16), (4096, 4096, 125, 0, 16), (4096, 4096, 32, 0, 16), (4096, 4096, 16, 0, 16), (4096, 4096, 8, 0, 16), (4096, 4096, 1, 0, 16), (4096, 2160, 113, 0, 16), (4096, 2160, 8, 0, 16), (1920, 1080, 480, 0, 16), (2048, 1536, 320, 4, 12), (1280, 800, 32, 4, 12), (1280, 800, 1000, 4, 12)]
 for xs, ys, n, shift, bits in cases:
     base = synth.plasma_frames(9, xs, ys, bits=bits, seed=3)
     d = torch.from_numpy(base[1:].reshape(8, -1).view(np.int16)).cuda()

@@ -184,6 +184,87 @@ def _run_group(cmd, env, timeout):
     return p.returncode, out, err
 
 
+class PowerSampler:
+    """tools/power_sampler.py as a child process (rocm-smi power / clock samples, amd-smi throttle accumulators), started
+    before this process touches the GPU and talked to over pipes; every failure ends in None, never in an exception."""
+
+    def __init__(self, gpu):
+        import subprocess
+        self.p = None
+        try:
+            self.p = subprocess.Popen([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "power_sampler.py"), str(gpu)],
+                                      stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, cwd="/tmp")
+        except Exception:
+            self.p = None
+
+    def ask(self, cmd, timeout=20.0):
+        import select
+        if self.p is None or self.p.poll() is not None:
+            return None
+        try:
+            self.p.stdin.write(cmd + "\n")
+            self.p.stdin.flush()
+            if not select.select([self.p.stdout], [], [], timeout)[0]:
+                return None
+            return json.loads(self.p.stdout.readline())
+        except Exception:
+            return None
+
+    def close(self):
+        if self.p is None:
+            return
+        try:
+            self.p.stdin.write("quit\n")
+            self.p.stdin.flush()
+            self.p.wait(timeout=10)
+        except Exception:
+            try:
+                self.p.kill()   # this child, by its pid
+            except Exception:
+                pass
+        self.p = None
+
+
+def power_phase(ps, loops, seconds=2.5):
+    """Socket power, shader clock and the share of time the firmware reports a package-power (PPT) violation while each
+    kernel of `loops` (name -> callable returning ms per batch) runs back to back for `seconds`."""
+    res = {}
+    ps.ask("on")
+    for name, fn in loops:
+        a = ps.ask("throttle")
+        t0, ms = time.time(), []
+        while time.time() - t0 < seconds:
+            ms.append(fn())
+        t1 = time.time()
+        b = ps.ask("throttle")
+        sm = ps.ask("samples")
+        s = [x for x in (sm or {}).get("samples", []) if t0 + 0.6 < x[0] < t1 - 0.1]
+        def moved(key):   # an accumulator's ticks (milliseconds) over the loop's duration
+            if a and b and isinstance(a.get(key), (int, float)) and isinstance(b.get(key), (int, float)):
+                return round((b[key] - a[key]) / ((t1 - t0) * 1e3), 3)
+            return None
+        frac = moved("ppt_acc")
+        res[name] = {"ms_per_batch": round(float(np.median(ms)), 4), "seconds": round(t1 - t0, 2),
+                     "socket_W": round(float(np.median([x[2] for x in s])), 0) if s else None,
+                     "sclk_MHz": round(float(np.median([x[1] for x in s])), 0) if s else None, "samples": len(s),
+                     "ppt_violation_frac": frac, "clk_below_limit_frac": moved("clk_below_limit_acc"),
+                     "clk_below_limit_power_frac": moved("clk_below_limit_power_acc"), "clk_below_limit_thermal_frac": moved("clk_below_limit_thermal_acc"),
+                     "low_utilization_frac": moved("low_utilization_acc"),
+                     "thermal_or_prochot_frac": max((moved(k) or 0.0) for k in ("socket_thermal_acc", "hbm_thermal_acc", "vr_thermal_acc", "prochot_acc"))}
+    sm = ps.ask("samples")
+    allw = [x[2] for x in (sm or {}).get("samples", [])]
+    cap = ps.ask("cap")
+    res["idle_W"] = min(allw) if allw else None
+    res["cap_W"] = (cap or {}).get("cap_W")
+    res["note"] = ("rocm-smi socket power / shader clock (median of the samples inside each loop) and the firmware's throttle accumulators (amd-smi "
+                   "metric --throttle: milliseconds in a package-power (PPT) violation, with the shader clock below its limit -- for any reason, for "
+                   "power, for temperature --, in a thermal / PROCHOT violation) over the loop's duration (the two amd-smi calls around a loop add about "
+                   "a second of idle to the window: low_utilization_frac); idle_W = the lowest sample of the run.  "
+                   "profiles/r05_power_probe.log, DESIGN.md section 4: by box the power limit is engaged for 1 % to a third of either kernel's time at "
+                   "nearly the same kernel times -- it is not what bounds them; a run that is throttled shows here")
+    return res
+
+
 def pmc_traffic(frames, workload="plasma"):
     """HBM bytes per launch of the forward kernels from rocprofv3 PMC counters, measured by two
     child runs of this script (FETCH_SIZE and WRITE_SIZE do not fit one pass; --pmc only, no trace
@@ -284,6 +365,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-large", action="store_true", help="skip the 4096x4096 figure (large_frames)")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-power", action="store_true", help="skip the power block (rocm-smi / amd-smi beside the kernels, 8 s)")
     ap.add_argument("--placement-survey", type=int, default=3,
                     help="AFTER the measurement: further buffer sets allocated one at a time, timed and freed, reported "
                          "next to the set `value` was measured on (the first allocation, what any context gets); 0 = none")
@@ -314,7 +396,11 @@ def main():
     dist = None
     # HBM traffic of the kernels from PMC counters: child processes under rocprofv3, started
     # before this process initialises the GPU
-    pmc = pmc_noise = multi = None
+    pmc = pmc_noise = multi = psamp = None
+    if rank == 0 and world == 1 and not args.quick and not args.no_power and args.frames == NFRAMES:
+        import atexit
+        psamp = PowerSampler(local_rank)
+        atexit.register(psamp.close)
     if rank == 0 and world == 1 and not args.no_pmc and not args.quick and args.frames == NFRAMES:
         pmc = pmc_traffic(args.frames)
         pmc_noise = pmc_traffic(args.frames, "noise")
@@ -323,6 +409,8 @@ def main():
     # call; the other ranks wait for it at the process group's first barrier.
     if rank == 0 and world > 1 and not args.no_e2e and not args.quick:
         multi = e2e_multi(world, args.share_gpu, host_threads())
+    if psamp is not None:
+        psamp.ask("off")   # nothing polls the GPU's firmware while the headline is timed; on again for the power block
     if args.share_gpu:
         local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
@@ -469,7 +557,7 @@ def main():
 
     # Decode direction on the same batch (secondary figure, not `value`): the inverse
     # predictor (DecompressImage's pixel loops, cc:326-344) over the planes just made.
-    inv = None
+    inv = power = None
     if rank == 0:
         # the decoded delta frame is the left-aligned delta image (cc:437-443 then cc:340-341)
         pred.set_delta_decoded((base[0].astype(np.uint16) << SHIFT).astype(np.uint16))
@@ -519,6 +607,14 @@ def main():
                         "sits on the latency of one frame's chain (smaller_batches: the time per batch hardly moves), so the GPU time per frame "
                         "falls with the batch size -- and stays 20-30x below the host's Brotli time per frame (6 ms per frame and thread) "
                         "even at 32, which is why the default stays where the pinned memory is small"}
+        if psamp is not None:
+            try:
+                power = power_phase(psamp, (("forward", lambda: pred.time_predict(d_frames, out, 20) / 20),
+                                            ("inverse", lambda: pred.time_inverse(out[0], out[1], out[3], rec, 20) / 20)))
+            except Exception as e:   # never the bench's problem
+                power = {"error": str(e)[:200]}
+            psamp.close()
+            psamp = None
         del rec
 
     # Adversarial forward workload (secondary figure): config-0 style noise at the full frame
@@ -661,6 +757,8 @@ def main():
         }
         if inv is not None:
             res["inverse"] = inv
+            if power is not None:
+                res["power"] = power
         if adv is not None:
             res["adversarial"] = adv
         if large is not None:

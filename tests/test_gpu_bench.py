@@ -65,6 +65,14 @@ def test_bench_line_contract():
         assert k in cb, k
     assert cb["kind"] in ("reference", "port") and cb["cores"] == 1 and cb["value"] > 0
     assert d["inverse"]["roundtrip_bit_exact"] is True
+    # the power block: present whatever the box offers; where rocm-smi is there, each loop has its samples, and a loaded chip
+    # draws more than an idle one
+    pw = d["power"]
+    assert "error" not in pw and set(("forward", "inverse", "idle_W", "cap_W")) <= set(pw), pw
+    if shutil.which("rocm-smi") is not None:
+        for k in ("forward", "inverse"):
+            assert pw[k]["samples"] >= 2 and pw[k]["socket_W"] > pw["idle_W"] + 100 and 0.3 < pw[k]["ms_per_batch"] < 1.5, pw
+            assert pw[k]["ppt_violation_frac"] is None or 0.0 <= pw[k]["ppt_violation_frac"] <= 1.0, pw
 
 
 def test_two_rank_line_carries_what_the_north_star_asks_for():

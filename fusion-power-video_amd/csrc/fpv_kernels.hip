@@ -1709,7 +1709,7 @@ static hipError_t predict_impl(const Geom& g, const uint16_t* d_frames,
     a.shift = (uint32_t)g.shift; a.nframes = nframes; a.with_delta = (uint32_t)with_delta;
     a.in_pitch = a.out_pitch = g.npix;
     a.xs15 = g.xs % 15u; a.xs31 = g.xs % 31u; a.c31 = (g.xs + 1u) % 31u; a.ncg = g.ncg;
-    a.dparts = 1u;
+    a.dparts = 1u; a.xband = 0u;
     TilePtrs& P = L.P;
     P.frames = d_frames; P.dhigh = d_dhigh; P.dlow = d_dlow;
     P.high = d_high; P.low = d_low; P.preview = d_preview; P.flags = d_flags;
@@ -1769,7 +1769,15 @@ static hipError_t predict_impl(const Geom& g, const uint16_t* d_frames,
 #if FPV_TILE_XGROUP > 1  // experiment: a flat grid
     const dim3 tgrid(nframes * g.tile_tiles);
 #else
-    const dim3 tgrid(g.tile_tiles << a.lfgroup, (nframes + (1u << a.lfgroup) - 1u) >> a.lfgroup);  // x fastest; nframes <= 65535 (create_impl)
+    // Small batches of large frames (the Encoder hands over 8 frames of 4096x4096 at a time): with the frames of a group spread
+    // over the eight XCDs, every XCD fetches every tile's delta bytes -- as many bytes again as the frames' own.  Then XCD c (the
+    // workgroups go to them round robin) walks its own eighth of the tiles, for all frames of the group: each delta byte is
+    // fetched once.  4096x4096: 1 frame -11 %, 4 frames -25 %, 8 frames -8 ... -21 % by size, 16 frames -2.5 %; above that it
+    // depends on the batch size and the box (32 frames +6 %, 60 frames -3.5 / +2.6 %, 125 frames +1.4 ... +2.5 %): not used there
+    // (profiles/r05_forward_ab.log).  FPV_TILE_XBAND=0 / 1 (read per launch): never / whenever the frames go in groups.
+    a.xband = a.lfgroup && nframes <= 16u ? 1u : 0u;
+    if (const char* e = getenv("FPV_TILE_XBAND")) a.xband = a.lfgroup && atoi(e) ? 1u : 0u;
+    const dim3 tgrid((a.xband ? 8u * ((g.tile_tiles + 7u) / 8u) : g.tile_tiles) << a.lfgroup, (nframes + (1u << a.lfgroup) - 1u) >> a.lfgroup);  // x fastest; nframes <= 65535 (create_impl)
 #endif
     if (lowp) k_tile<SWAP, true><<<tgrid, T, lds, s>>>(L);
     else k_tile<SWAP, false><<<tgrid, T, lds, s>>>(L);

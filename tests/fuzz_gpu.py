@@ -80,7 +80,7 @@ while time.time() - t0 < budget:
     os.environ["FPV_TRIO_RES"] = str(rng.choice(["1", "0"], p=[0.7, 0.3]))   # north operands in registers where the row is one superstep long (256, 1280, 1536 wide here)
     # forward path (read when the context is created): the tile pass with a random tile height where the
     # width allows it (multiples of 64), now and then the streaming kernels instead
-    for k in ("FPV_TILE_GROUPS", "FPV_FORWARD", "FPV_TILE8_GROUPS", "FPV_TILE8_ROWS", "FPV_TILE_FGROUP", "FPV_DECIDE_PARTS"):
+    for k in ("FPV_TILE_GROUPS", "FPV_FORWARD", "FPV_TILE8_GROUPS", "FPV_TILE8_ROWS", "FPV_TILE_FGROUP", "FPV_DECIDE_PARTS", "FPV_TILE_XBAND"):
         os.environ.pop(k, None)
     if rng.integers(0, 3) == 0:   # k_tile_decide: several workgroups per frame, the last to arrive decides (read per launch)
         os.environ["FPV_DECIDE_PARTS"] = str(rng.choice(["2", "4", "8"]))
@@ -89,8 +89,9 @@ while time.time() - t0 < budget:
         os.environ["FPV_FORWARD"] = "stream"
     elif r < 4:     # the tile pass (16 pixels per lane) at a random tile height (default height otherwise),
         os.environ["FPV_TILE_GROUPS"] = str(int(rng.integers(1, 24)))
-        if rng.integers(0, 2):   # ... in groups of frames walked tile by tile (the order large frames take)
+        if rng.integers(0, 2):   # ... in groups of frames walked tile by tile (the order large frames take), band-wise per XCD or not
             os.environ["FPV_TILE_FGROUP"] = str(int(rng.integers(0, 4)))
+            os.environ["FPV_TILE_XBAND"] = str(int(rng.integers(0, 2)))
     elif r < 8:     # round 4's variant (8 pixels per lane): 4 or 8 rows per thread, random tile height
         os.environ["FPV_FORWARD"] = "tile8"
         os.environ["FPV_TILE8_ROWS"] = str(int(rng.choice([4, 8])))

@@ -123,13 +123,18 @@ def test_alternate_kernel_paths(fpv, synth, oracle, env):
 
 @pytest.mark.parametrize("xs,ys,n,env,want", [
     (512, 40, 6, {"FPV_TILE_FGROUP": "2"}, 2), (1280, 48, 5, {"FPV_TILE_FGROUP": "3", "FPV_TILE_GROUPS": "5"}, 3), (4096, 24, 6, {"FPV_TILE_FGROUP": "1"}, 1),
-    (4096, 1032, 3, {}, 6), (2048, 1536, 2, {}, 0)])
+    (4096, 1032, 3, {}, 6), (2048, 1536, 2, {}, 0),
+    (512, 40, 6, {"FPV_TILE_FGROUP": "2", "FPV_TILE_XBAND": "1"}, 2), (1280, 48, 5, {"FPV_TILE_FGROUP": "3", "FPV_TILE_GROUPS": "1", "FPV_TILE_XBAND": "1"}, 3),
+    (4096, 24, 6, {"FPV_TILE_FGROUP": "1", "FPV_TILE_XBAND": "1"}, 1), (320, 200, 7, {"FPV_TILE_FGROUP": "2", "FPV_TILE_GROUPS": "1", "FPV_TILE_XBAND": "1"}, 2),
+    (320, 68, 3, {"FPV_TILE_FGROUP": "1", "FPV_TILE_GROUPS": "1", "FPV_TILE_XBAND": "1"}, 1), (4096, 1032, 3, {"FPV_TILE_XBAND": "0"}, 6)])
 def test_large_frame_order(fpv, synth, oracle, xs, ys, n, env, want):
     """Frames whose delta planes pass 8 MB are walked in groups of frames TILE BY TILE (the frame of the
     group fastest; grid = (tiles << k, groups)) instead of frame by frame; forced here on small frames
     too (FPV_TILE_FGROUP=k) with batches that leave the last group short -- its empty slots are
-    workgroups that leave at once -- and with a partial last tile.  Noise (the CG decision flips,
-    frames are redone) and smooth frames, with and without a delta frame."""
+    workgroups that leave at once -- and with a partial last tile.  Small batches of such frames go band-wise
+    (FPV_TILE_XBAND: XCD c walks its own eighth of the tiles; by default up to 16 frames, so the 4096-wide cases here
+    take it): forced on and off, with tile counts below 8, not a multiple of 8 (3, 12, 50, 17 tiles) and 129.
+    Noise (the CG decision flips, frames are redone) and smooth frames, with and without a delta frame."""
     import os
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)

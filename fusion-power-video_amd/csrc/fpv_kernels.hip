@@ -1889,22 +1889,41 @@ static bool trio_ip_ok(const Geom& g, uint32_t k4) {  // a lane's north bytes mu
 // registers.  Taken for batches of up to 2.25 frames per CU -- where the chain wave is what a frame waits for: 32 ... 512 frames
 // -7 ... -10 %, 576 frames -3 %; from 640 frames on the batch is bound by HBM and the form costs 0 ... 1 % (profiles/r05_inverse_ab.log).
 // FPV_TRIO_RES (read per launch: A/B runs, tests): 0 never, 1 whatever the batch size.
-static bool trio_res_ok(const Geom& g, uint32_t k4, uint32_t mblk, uint32_t nframes) {
-  const char* e = getenv("FPV_TRIO_RES");
-  if (e && atoi(e) == 0) return false;
-  if (g.xs != 256 * k4 || (mblk & 1)) return false;
-  return e ? true : 4ull * nframes <= 9ull * device_cus();
+// Supersteps per row where the register-north form applies (0: it does not): rows of one superstep in blocks of an even
+// length, rows of 2 ... 4 supersteps (as many register sets + 1: 100 registers at most; segments of 20 or 24 pixels) in blocks of four.
+static uint32_t trio_res_rows(const Geom& g, uint32_t k4, uint32_t mblk) {
+  const uint32_t S = 256 * k4;
+  if (g.xs % S) return 0;
+  const uint32_t m = g.xs / S;
+  if (m == 1) return (mblk & 1) ? 0u : 1u;
+  return m <= 4 && k4 >= 5 && mblk == 4 && (m + 1) * 4 * k4 <= 100 ? m : 0u;
 }
-// The instantiation for (in place?, resonant?)
+static uint32_t trio_res_ok(const Geom& g, uint32_t k4, uint32_t mblk, uint32_t nframes) {
+  const char* e = getenv("FPV_TRIO_RES");
+  if (e && atoi(e) == 0) return 0;
+  const uint32_t m = trio_res_rows(g, k4, mblk);
+  if (!m) return 0;
+  return e || 4ull * nframes <= 9ull * device_cus() ? m : 0u;
+}
+// The instantiation for (in place?, register-north form: supersteps per row, 0 = not)
 template <int K4, int MB>
-static auto trio_kernel(bool ip, bool res) -> decltype(&k_inverse_trio<K4, MB, false, false>) {
+static auto trio_kernel(bool ip, uint32_t res) -> decltype(&k_inverse_trio<K4, MB, false, 0>) {
   if (ip) {
     if constexpr (MB % 2 == 0) {
-      if (res) return &k_inverse_trio<K4, MB, true, true>;
+      if (res == 1) return &k_inverse_trio<K4, MB, true, 1>;
     }
-    return &k_inverse_trio<K4, MB, true, false>;
+    if constexpr (MB == 4 && K4 >= 5) {
+      if (res == 2) return &k_inverse_trio<K4, MB, true, 2>;
+      if constexpr (4 * 4 * K4 <= 100) {
+        if (res == 3) return &k_inverse_trio<K4, MB, true, 3>;
+      }
+      if constexpr (5 * 4 * K4 <= 100) {
+        if (res == 4) return &k_inverse_trio<K4, MB, true, 4>;
+      }
+    }
+    return &k_inverse_trio<K4, MB, true, 0>;
   }
-  return &k_inverse_trio<K4, MB, false, false>;
+  return &k_inverse_trio<K4, MB, false, 0>;
 }
 static uint32_t trio_ring(const Geom& g, uint32_t k4, uint32_t mblk, bool ip = false) {
   const uint32_t S = 256 * k4;
@@ -1950,7 +1969,7 @@ static uint32_t trio_capacity(const Geom& g, uint32_t k4, uint32_t mblk, bool ip
   if (!*cap_slot) {
     int blocks = 0;
     hipError_t e = hipErrorInvalidValue;
-#define FPV_OCC(K4, MB) if (k4 == K4 && mblk == MB) { const auto kfn = trio_kernel<K4, MB>(ip, false); e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kfn, 192, lds); }
+#define FPV_OCC(K4, MB) if (k4 == K4 && mblk == MB) { const auto kfn = trio_kernel<K4, MB>(ip, 0); e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kfn, 192, lds); }
 #define FPV_OCC3(K4) FPV_OCC(K4, 1) FPV_OCC(K4, 2) FPV_OCC(K4, 4)
     FPV_OCC3(1) FPV_OCC3(2) FPV_OCC3(3) FPV_OCC3(4) FPV_OCC3(5) FPV_OCC3(6)
 #undef FPV_OCC3
@@ -1999,6 +2018,9 @@ static int inverse_mode(const Geom& g, uint32_t nframes, uint32_t* k4, uint32_t*
     // passes run was built on top and is 3-15 % SLOWER: the backend waits for such loads in front of the pass loop.)
     const bool blk_env = getenv("FPV_TRIO_BLOCK") != nullptr;
     const uint32_t ipm = blk_env ? mmax : std::min(mmax, 2u);
+    // (Rows of 2 ... 4 supersteps take the register-north form as well where one of these two segment lengths divides the row
+    // -- 2560 wide at k4 = 5, 3072 at 6: -4.5 % --; going down to a length that does -- 4096 and 2048 wide at k4 = 4 -- costs more
+    // than the form returns: 8.17 against 7.67 ms per batch of 4096x4096, profiles/r05_inverse_ab.log.)
     for (uint32_t kk = g.spec_k4; kk + 1 >= g.spec_k4 && kk >= 1 && mode == 0; kk--) {
       if (!blk_env && mmax >= 4 && nframes <= 2 * device_cus() && trio_res_ok(g, kk, 4, nframes) && nframes <= trio_capacity(g, kk, 4, true)) { mode = 3; *k4 = kk; *mblk = 4; *ip = true; }
       else if (nframes <= trio_capacity(g, kk, ipm, true)) { mode = 3; *k4 = kk; *mblk = ipm; *ip = true; }
@@ -2061,7 +2083,7 @@ hipError_t launch_inverse(const Geom& g, const uint8_t* d_high,
 #endif
 #define FPV_LAUNCH_TRIO(K4, MB)                                                                       \
   if (k4 == K4 && mblk == MB) {                                                                       \
-    const auto kfn = trio_kernel<K4, MB>(ip, ip && trio_res_ok(g, K4, MB, nframes));                  \
+    const auto kfn = trio_kernel<K4, MB>(ip, ip ? trio_res_ok(g, K4, MB, nframes) : 0u);                  \
     kfn<<<nframes, 192, trio_lds(g, K4, MB, ip), s>>>(d_high, d_low, d_dhigh, d_dlow, d_flags, d_frames, FPV_TRIO_GEOM, \
                                                       trio_ring(g, K4, MB, ip), d_diag);             \
   }

@@ -223,6 +223,44 @@ def test_three_wave_block_lengths(fpv, oracle, block, xs, ys, n, inplace):
                 os.environ[k] = v
 
 
+@pytest.mark.parametrize("res", ["default", "0"])
+@pytest.mark.parametrize("xs,ys,n,k4", [(2560, 20, 9, 5), (3072, 16, 10, 6), (3840, 12, 7, 0), (5120, 12, 6, 5), (4608, 12, 6, 6),
+                                          (3072, 4, 5, 6), (2560, 4, 3, 5), (4096, 20, 12, 0), (2048, 24, 12, 0)])
+def test_rows_of_several_supersteps(fpv, oracle, inverse_kernel, xs, ys, n, k4, res):
+    """Rows that are 2, 3 or 4 supersteps long: the three-wave kernel keeps the north operands in registers there too
+    (m + 1 register sets taking turns; round 5) where the geometry's segment length, or the one below it, divides the
+    row (2560 / 5120 wide: 20-pixel segments; 3072 / 4608: 24; 3840 wide divides by both and stays at 24 with the ring form), for batches the chain bounds; 4096 and 2048 wide
+    would need 16-pixel segments and stay with the ring form (k4 = 0 here: either of the geometry's own lengths).
+    Frames with about as many supersteps as a row has (four rows), superstep counts that are no multiple of m + 1 or of
+    the block, flags of every kind, long identity runs; FPV_TRIO_RES=0: the same frames with the north bytes from the
+    ring.  The superstep count of the batch tells which segment length ran."""
+    old = os.environ.get("FPV_TRIO_RES")
+    if res == "0":
+        os.environ["FPV_TRIO_RES"] = "0"
+    else:
+        os.environ.pop("FPV_TRIO_RES", None)
+    try:
+        rng = np.random.default_rng(xs + ys * 5 + n)
+        high = rng.integers(0, 256, (n, ys, xs), dtype=np.uint8)
+        high[::3] = (rng.integers(0, 40, (len(high[::3]), ys, xs)) == 0) * 7
+        low = rng.integers(0, 256, (n, ys, xs), dtype=np.uint8)
+        delta16 = rng.integers(0, 65536, ys * xs).astype(np.uint16)
+        flags = (np.arange(n) % 8).astype(np.uint8)
+        steps, passes = _inverse_case(fpv, oracle, high, low, flags, xs, ys, delta16)
+        if inverse_kernel == "trio":
+            own = min(6, xs // 256)   # the geometry's own segment length; the in-place form may run one below it (xs % (4 k4) == 0)
+            fits = []
+            for kk in ((k4,) if res == "default" and k4 else (own, own - 1)):
+                per_frame = -(-(xs * ys - min(xs + 4, xs * ys)) // (256 * kk))   # the pixels behind the head (first row + 4), in supersteps
+                fits.append((steps == 0) if per_frame == 0 else (steps % per_frame == 0 and 1 <= steps // per_frame <= n))
+            assert any(fits), (steps, res, k4, own)
+    finally:
+        if old is None:
+            os.environ.pop("FPV_TRIO_RES", None)
+        else:
+            os.environ["FPV_TRIO_RES"] = old
+
+
 def test_chain_simd_claim_fallback_and_recovery(fpv, oracle):
     """The three-wave kernel's workgroups claim a SIMD that no other frame's chain wave is on, in a
     per-CU word of device memory -- a placement hint only.  With every SIMD marked taken (what a

@@ -53,7 +53,10 @@ def test_no_kernel_spills_and_register_budgets_hold(tmp_path):
     # latter in blocks of four, <5, 4, true, true>, is what partial batches take: three workgroups per CU are enough there)
     k52 = [k for n, k in ks.items() if "k_inverse_trioILi5ELi2ELb1E" in n]
     assert len(k52) == 2 and all(k["vgpr_count"] + k["agpr_count"] <= 168 for k in k52), k52
-    k54 = [k for n, k in ks.items() if "k_inverse_trioILi5ELi4ELb1ELb1E" in n]
+    k54 = [k for n, k in ks.items() if "k_inverse_trioILi5ELi4ELb1ELi1E" in n]
     assert len(k54) == 1 and k54[0]["vgpr_count"] + k54[0]["agpr_count"] <= 168, k54
-    k44 = [k for n, k in ks.items() if "k_inverse_trioILi4ELi4E" in n]
+    k44 = [k for n, k in ks.items() if "k_inverse_trioILi4ELi4ELb" in n and ("ELi0EEE" in n or "ELi1EEE" in n)]
     assert len(k44) == 3 and all(k["vgpr_count"] + k["agpr_count"] <= 128 for k in k44), k44
+    # rows of 2 ... 4 supersteps (m + 1 register sets): partial batches only, at most two workgroups per CU -- no spills
+    multi = [k for n, k in ks.items() if "k_inverse_trioILi" in n and any(f"ELb1ELi{m}EEE" in n for m in (2, 3, 4))]
+    assert len(multi) == 5 and all(k["vgpr_count"] + k["agpr_count"] <= 256 and k.get("vgpr_spill_count", 0) == 0 for k in multi), multi

@@ -225,12 +225,15 @@ def test_three_wave_block_lengths(fpv, oracle, block, xs, ys, n, inplace):
 
 @pytest.mark.parametrize("res", ["default", "0"])
 @pytest.mark.parametrize("xs,ys,n,k4", [(2560, 20, 9, 5), (3072, 16, 10, 6), (3840, 12, 7, 0), (5120, 12, 6, 5), (4608, 12, 6, 6),
-                                          (3072, 4, 5, 6), (2560, 4, 3, 5), (4096, 20, 12, 0), (2048, 24, 12, 0)])
+                                          (3072, 4, 5, 6), (2560, 4, 3, 5), (4096, 20, 12, 8), (2048, 24, 12, 8), (6144, 8, 5, 8),
+                                          (4096, 4, 5, 8), (2048, 4, 3, 8), (2048, 8, 300, 8)])
 def test_rows_of_several_supersteps(fpv, oracle, inverse_kernel, xs, ys, n, k4, res):
     """Rows that are 2, 3 or 4 supersteps long: the three-wave kernel keeps the north operands in registers there too
     (m + 1 register sets taking turns; round 5) where the geometry's segment length, or the one below it, divides the
-    row (2560 / 5120 wide: 20-pixel segments; 3072 / 4608: 24; 3840 wide divides by both and stays at 24 with the ring form), for batches the chain bounds; 4096 and 2048 wide
-    would need 16-pixel segments and stay with the ring form (k4 = 0 here: either of the geometry's own lengths).
+    row (2560 / 5120 wide: 20-pixel segments; 3072 / 4608: 24; 3840 wide divides by both and stays at 24 with the ring
+    form: k4 = 0 here, either of the geometry's own lengths), for batches the chain bounds.  Rows that are a multiple of
+    2048 pixels (2048, 4096, 6144 wide) run 32-pixel segments (k4 = 8: instantiated for this form only, blocks of two);
+    300 frames of 2048 x 8: more workgroups than compute units.
     Frames with about as many supersteps as a row has (four rows), superstep counts that are no multiple of m + 1 or of
     the block, flags of every kind, long identity runs; FPV_TRIO_RES=0: the same frames with the north bytes from the
     ring.  The superstep count of the batch tells which segment length ran."""

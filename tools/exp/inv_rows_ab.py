@@ -5,8 +5,9 @@ import importlib, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from __graft_entry__ import load_package
+ENVS = ({}, {"FPV_TRIO_WIDE": "0"}, {"FPV_TRIO_RES": "0"})
 pkg = load_package(); synth = importlib.import_module("fpv_amd.synth")
-for xs, ys, n, bits, shift in ((4096, 4096, 60, 16, 0), (4096, 4096, 8, 16, 0), (2048, 1536, 256, 12, 4), (2560, 2048, 128, 12, 4), (3072, 3072, 64, 16, 0), (1280, 800, 256, 12, 4)):
+for xs, ys, n, bits, shift in ((4096, 4096, 60, 16, 0), (4096, 4096, 8, 16, 0), (2048, 1536, 256, 12, 4), (2048, 1536, 512, 12, 4), (2048, 2048, 32, 16, 0), (2560, 2048, 128, 12, 4), (3072, 3072, 64, 16, 0), (1280, 800, 256, 12, 4)):
     base = synth.plasma_frames(9, xs, ys, bits=bits, seed=3)
     d = torch.from_numpy(base[1:].reshape(8, -1).view(np.int16)).cuda()
     fr = d[torch.arange(n, device="cuda") % 8].contiguous().view(torch.uint16)
@@ -16,7 +17,7 @@ for xs, ys, n, bits, shift in ((4096, 4096, 60, 16, 0), (4096, 4096, 8, 16, 0), 
     p.set_delta_decoded((base[0].astype(np.uint16) << shift).astype(np.uint16))
     rec = torch.empty((n, xs * ys), dtype=torch.uint16, device="cuda")
     res = {}
-    for env in ({}, {"FPV_TRIO_RES": "0"}):
+    for env in ENVS:
         os.environ.update(env)
         rec.zero_()
         p.inverse_pass_stats(reset=True)
@@ -27,7 +28,7 @@ for xs, ys, n, bits, shift in ((4096, 4096, 60, 16, 0), (4096, 4096, 8, 16, 0), 
         res[str(env)] = [ok, st, []]
         for k in env: os.environ.pop(k)
     for _ in range(5):
-        for env in ({}, {"FPV_TRIO_RES": "0"}):
+        for env in ENVS:
             os.environ.update(env)
             res[str(env)][2].append(p.time_inverse(planes[0], planes[1], planes[3], rec, 5) / 5)
             for k in env: os.environ.pop(k)

@@ -64,7 +64,7 @@ while time.time() - t0 < budget:
     xs = int(rng.choice([rng.integers(1, 40) * 4, rng.integers(64, 520) * 4, 256, 1280, 1536]))
     ys = int(rng.integers(1, 24)) * 4
     if big:
-        xs = int(rng.choice([1920, 2560, 4096, rng.integers(400, 2049) * 4]))   # encode side: xsize <= 8192
+        xs = int(rng.choice([1920, 2560, 4096, 2048, 3072, 6144, rng.integers(400, 2049) * 4]))   # encode side: xsize <= 8192
         ys = int(rng.integers(8, 80)) * 4
     be = bool(rng.integers(0, 2))
     shift = int(rng.choice([0, 0, 4, 8, 2, 6])) if be else int(rng.choice([0, 0, 4, 8, 2, 6, 12]))
@@ -75,8 +75,11 @@ while time.time() - t0 < budget:
     delta = fr[0] if rng.integers(0, 5) else None
     os.environ["FPV_INVERSE"] = str(rng.choice(["spec", "trio", "auto", "fast"], p=[0.4, 0.4, 0.1, 0.1]))  # read per launch
     # the three-wave kernel: blocks of 1 / 2 / 4 supersteps, residuals in the ring two blocks ahead (round 5) or in their own slots
-    os.environ["FPV_TRIO_BLOCK"] = str(rng.choice(["1", "2", "4"]))
+    os.environ.pop("FPV_TRIO_BLOCK", None)
+    if rng.integers(0, 3):    # (unset: the library's own choice, which alone takes the 32-pixel segments)
+        os.environ["FPV_TRIO_BLOCK"] = str(rng.choice(["1", "2", "4"]))
     os.environ["FPV_TRIO_INPLACE"] = str(rng.choice(["1", "0"], p=[0.7, 0.3]))
+    os.environ["FPV_TRIO_WIDE"] = str(rng.choice(["1", "0"], p=[0.8, 0.2]))   # 32-pixel segments on rows that are multiples of 2048 pixels (auto kernel choice only)
     os.environ["FPV_TRIO_RES"] = str(rng.choice(["1", "0"], p=[0.7, 0.3]))   # north operands in registers where the row is one superstep long (256, 1280, 1536 wide here)
     # forward path (read when the context is created): the tile pass with a random tile height where the
     # width allows it (multiples of 64), now and then the streaming kernels instead

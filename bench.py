@@ -701,6 +701,21 @@ def main():
                 lres[tag] = min(pl.time_predict(lfr, lout, 10) / 10 for _ in range(3))
                 lnames = pl.forward_kernel_names()
                 lflags = lout[3].cpu().numpy()
+                if not env:   # the decode direction on the same planes: one frame's chain is what a batch of 60 waits for
+                    pl.set_delta_decoded(lbase0)
+                    lrec = torch.empty((ln, lx * ly), dtype=torch.uint16, device=dev)
+                    pl.inverse(lout[0], lout[1], lout[3], out=lrec)
+                    torch.cuda.synchronize()
+                    linv = {"roundtrip_bit_exact": bool((lrec.view(torch.int16) == lfr.view(torch.int16).view(ln, lx * ly)).all()),
+                            "kernel": pl.inverse_kernel_name(ln)}
+                    linv["ms_per_batch"] = round(pl.time_inverse(lout[0], lout[1], lout[3], lrec, 3) / 3, 4)
+                    os.environ["FPV_TRIO_WIDE"] = "0"
+                    linv["ms_per_batch_24_pixel_segments"] = round(pl.time_inverse(lout[0], lout[1], lout[3], lrec, 3) / 3, 4)
+                    os.environ.pop("FPV_TRIO_WIDE")
+                    linv["ns_per_pixel_of_one_frame"] = round(1e6 * linv["ms_per_batch"] / (lx * ly), 4)
+                    linv["note"] = ("a batch this small is bound by one frame's serial chain (the three-wave kernel, north operands in registers, 32-pixel "
+                                    "segments: rows of 4096 pixels are two supersteps; FPV_TRIO_WIDE=0: the ring form at the geometry's 24-pixel segments)")
+                    del lrec
                 pl.close()
             lms = lres["groups_of_64_frames_tile_by_tile"]
             lbytes = ln * lx * ly * 4.0625
@@ -708,7 +723,7 @@ def main():
                      "flags_histogram": {str(k): int(v) for k, v in zip(*np.unique(lflags, return_counts=True))},
                      "ms_per_step": round(lms, 4), "frames_per_s": round(ln / lms * 1e3, 1),
                      "algorithmic_GBps_all_kernels": round(lbytes / lms / 1e6, 1), "frac_all_kernels": round(lbytes / lms / 1e6 / HBM_PEAK_GBPS, 4),
-                     "ms_per_step_frame_by_frame": round(lres["frame_by_frame"], 4), "kernels": lnames,
+                     "ms_per_step_frame_by_frame": round(lres["frame_by_frame"], 4), "kernels": lnames, "inverse": linv,
                      "note": "default order for frames whose delta planes pass 8 MB: groups of 64 frames walked tile by tile, so that a tile's "
                              "delta bytes are fetched once per group; frame by frame (FPV_TILE_FGROUP=0, the order of smaller frames) every "
                              "frame re-reads the 33.5 MB of delta planes"}

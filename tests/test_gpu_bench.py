@@ -54,6 +54,7 @@ def test_bench_line_contract():
     lf = d["large_frames"]
     assert "error" not in lf, lf
     assert lf["flags_histogram"] == {"3": 60} and lf["ms_per_step"] < 0.95 * lf["ms_per_step_frame_by_frame"], lf
+    assert lf["inverse"]["roundtrip_bit_exact"] is True and lf["inverse"]["ms_per_batch"] < 0.95 * lf["inverse"]["ms_per_batch_24_pixel_segments"], lf["inverse"]
     mv = d["value_moving_window"]
     assert mv["frames_redone_per_step"] > 0 and 0.5 * d["value"] < mv["frames_per_s"] <= 1.05 * d["value"], mv
     # `value` comes from the first allocation; the survey is reported, never selected

@@ -1895,7 +1895,7 @@ static uint32_t trio_res_rows(const Geom& g, uint32_t k4, uint32_t mblk) {
   const uint32_t S = 256 * k4;
   if (g.xs % S) return 0;
   const uint32_t m = g.xs / S;
-  if (k4 == kTrioWideK4) return m <= 3 && mblk == 2 ? m : 0u;   // 32-pixel segments (2048 / 4096 / 6144 wide): this form only, blocks of two
+  if (k4 > kSpecMaxK4) return m <= trio_wide_rows(k4) && mblk == 2 ? m : 0u;   // 32 / 40 / 48-pixel segments: this form only, blocks of two
   if (m == 1) return (mblk & 1) ? 0u : 1u;
   return m <= 4 && k4 >= 5 && mblk == 4 && (m + 1) * 4 * k4 <= 100 ? m : 0u;
 }
@@ -1909,9 +1909,13 @@ static uint32_t trio_res_ok(const Geom& g, uint32_t k4, uint32_t mblk, uint32_t 
 // The instantiation for (in place?, register-north form: supersteps per row, 0 = not)
 template <int K4, int MB>
 static auto trio_kernel(bool ip, uint32_t res) -> decltype(&k_inverse_trio<K4, MB, true, 1>) {
-  if constexpr (K4 == (int)kTrioWideK4) {   // the register-north forms only
-    if (res == 2) return &k_inverse_trio<K4, MB, true, 2>;
-    if (res == 3) return &k_inverse_trio<K4, MB, true, 3>;
+  if constexpr (K4 > (int)kSpecMaxK4) {   // the register-north forms only
+    if constexpr (trio_wide_rows(K4) >= 2) {
+      if (res == 2) return &k_inverse_trio<K4, MB, true, 2>;
+    }
+    if constexpr (trio_wide_rows(K4) >= 3) {
+      if (res == 3) return &k_inverse_trio<K4, MB, true, 3>;
+    }
     return &k_inverse_trio<K4, MB, true, 1>;
   } else {
     if (ip) {
@@ -1950,11 +1954,11 @@ static uint32_t trio_capacity(const Geom& g, uint32_t k4, uint32_t mblk, bool ip
   // (k4, mblk) alone: a second context with another width must not reuse the first one's figure.
   struct Slot { uint32_t lds, cap; };
   static std::mutex m;
-  static Slot capm[64][2][kTrioWideK4 + 1][5][4] = {};  // a few widths per instantiation; beyond that the oldest entry is replaced
+  static Slot capm[64][2][kTrioWideMaxK4 + 1][5][4] = {};  // a few widths per instantiation; beyond that the oldest entry is replaced
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) dev = 0;
   dev &= 63;
-  if (k4 == 0 || (k4 > kSpecMaxK4 && !(k4 == kTrioWideK4 && mblk == 2 && ip)) || (mblk != 1 && mblk != 2 && mblk != 4)) return 0;
+  if (k4 == 0 || (k4 > kSpecMaxK4 && !(trio_wide_rows(k4) && mblk == 2 && ip)) || (mblk != 1 && mblk != 2 && mblk != 4)) return 0;
   if (ip && !trio_ip_ok(g, k4)) return 0;
   const size_t lds = trio_lds(g, k4, mblk, ip);
   if (lds > 64 * 1024) return 0;
@@ -1976,9 +1980,9 @@ static uint32_t trio_capacity(const Geom& g, uint32_t k4, uint32_t mblk, bool ip
   if (!*cap_slot) {
     int blocks = 0;
     hipError_t e = hipErrorInvalidValue;
-#define FPV_OCC(K4, MB) if (k4 == K4 && mblk == MB) { const auto kfn = trio_kernel<K4, MB>(ip, K4 == 8 ? trio_res_rows(g, K4, MB) : 0u); e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kfn, 192, lds); }
+#define FPV_OCC(K4, MB) if (k4 == K4 && mblk == MB) { const auto kfn = trio_kernel<K4, MB>(ip, K4 > 6 ? trio_res_rows(g, K4, MB) : 0u); e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kfn, 192, lds); }
 #define FPV_OCC3(K4) FPV_OCC(K4, 1) FPV_OCC(K4, 2) FPV_OCC(K4, 4)
-    FPV_OCC3(1) FPV_OCC3(2) FPV_OCC3(3) FPV_OCC3(4) FPV_OCC3(5) FPV_OCC3(6) FPV_OCC(8, 2)
+    FPV_OCC3(1) FPV_OCC3(2) FPV_OCC3(3) FPV_OCC3(4) FPV_OCC3(5) FPV_OCC3(6) FPV_OCC(8, 2) FPV_OCC(10, 2) FPV_OCC(12, 2)
 #undef FPV_OCC3
 #undef FPV_OCC
     if (e != hipSuccess || blocks <= 0) blocks = 3;
@@ -2025,10 +2029,12 @@ static int inverse_mode(const Geom& g, uint32_t nframes, uint32_t* k4, uint32_t*
     // passes run was built on top and is 3-15 % SLOWER: the backend waits for such loads in front of the pass loop.)
     const bool blk_env = getenv("FPV_TRIO_BLOCK") != nullptr;
     const uint32_t ipm = blk_env ? mmax : std::min(mmax, 2u);
-    // Rows that are a multiple of 2048 pixels (2048, 4096, 6144 wide): segments of 32 pixels per lane (k4 = 8, this form only,
-    // blocks of two: 35 KB of LDS), where the geometry's own length (24) does not divide the row.  FPV_TRIO_WIDE=0: never.
-    if (!blk_env && nframes <= 2 * device_cus() && !(getenv("FPV_TRIO_WIDE") && atoi(getenv("FPV_TRIO_WIDE")) == 0) && trio_res_ok(g, kTrioWideK4, 2, nframes) &&
-        nframes <= trio_capacity(g, kTrioWideK4, 2, true)) { mode = 3; *k4 = kTrioWideK4; *mblk = 2; *ip = true; }
+    // Rows that are 1 ... 3 times 2048 pixels (2048, 4096, 6144 wide), 1 or 2 times 2560, or 3072 pixels: segments of 32 / 40 / 48
+    // pixels per lane (k4 = 8 / 10 / 12, this form only, blocks of two: 35 ... 49 KB of LDS): the longer the segment, the fewer
+    // supersteps and the fewer passes each (4096x4096: 7.68 -> 6.13 ms per batch).  FPV_TRIO_WIDE=0: never.
+    if (!blk_env && nframes <= 2 * device_cus() && !(getenv("FPV_TRIO_WIDE") && atoi(getenv("FPV_TRIO_WIDE")) == 0))
+      for (uint32_t kk = kTrioWideMaxK4; kk > kSpecMaxK4 && mode == 0; kk -= 2)   // 48, 40, 32 pixels per lane: the longest that fits the row
+        if (trio_res_ok(g, kk, 2, nframes) && nframes <= trio_capacity(g, kk, 2, true)) { mode = 3; *k4 = kk; *mblk = 2; *ip = true; }
     // (Rows of 2 ... 4 supersteps take the register-north form as well where one of these two segment lengths divides the row
     // -- 2560 wide at k4 = 5, 3072 at 6: -4.5 % --; going down to a length that does -- 4096 and 2048 wide at k4 = 4 -- costs more
     // than the form returns: 8.17 against 7.67 ms per batch of 4096x4096, profiles/r05_inverse_ab.log.)
@@ -2094,14 +2100,14 @@ hipError_t launch_inverse(const Geom& g, const uint8_t* d_high,
 #endif
 #define FPV_LAUNCH_TRIO(K4, MB)                                                                       \
   if (k4 == K4 && mblk == MB) {                                                                       \
-    const auto kfn = trio_kernel<K4, MB>(ip, K4 == 8 ? trio_res_rows(g, K4, MB) : ip ? trio_res_ok(g, K4, MB, nframes) : 0u); \
+    const auto kfn = trio_kernel<K4, MB>(ip, K4 > 6 ? trio_res_rows(g, K4, MB) : ip ? trio_res_ok(g, K4, MB, nframes) : 0u); \
     kfn<<<nframes, 192, trio_lds(g, K4, MB, ip), s>>>(d_high, d_low, d_dhigh, d_dlow, d_flags, d_frames, FPV_TRIO_GEOM, \
                                                       trio_ring(g, K4, MB, ip), d_diag);             \
   }
 #define FPV_LAUNCH_TRIO3(K4) FPV_LAUNCH_TRIO(K4, 1) FPV_LAUNCH_TRIO(K4, 2) FPV_LAUNCH_TRIO(K4, 4)
-    if (k4 < 1 || (k4 > kSpecMaxK4 && !(k4 == kTrioWideK4 && mblk == 2 && ip && trio_res_rows(g, k4, mblk)))) return hipErrorInvalidValue;
+    if (k4 < 1 || (k4 > kSpecMaxK4 && !(mblk == 2 && ip && trio_res_rows(g, k4, mblk)))) return hipErrorInvalidValue;
     FPV_LAUNCH_TRIO3(1) FPV_LAUNCH_TRIO3(2) FPV_LAUNCH_TRIO3(3)
-    FPV_LAUNCH_TRIO3(4) FPV_LAUNCH_TRIO3(5) FPV_LAUNCH_TRIO3(6) FPV_LAUNCH_TRIO(8, 2)
+    FPV_LAUNCH_TRIO3(4) FPV_LAUNCH_TRIO3(5) FPV_LAUNCH_TRIO3(6) FPV_LAUNCH_TRIO(8, 2) FPV_LAUNCH_TRIO(10, 2) FPV_LAUNCH_TRIO(12, 2)
 #undef FPV_LAUNCH_TRIO3
 #undef FPV_LAUNCH_TRIO
   } else if (mode == 0 && g.spec_k4) {

@@ -224,19 +224,25 @@ def test_three_wave_block_lengths(fpv, oracle, block, xs, ys, n, inplace):
 
 
 @pytest.mark.parametrize("res", ["default", "0"])
-@pytest.mark.parametrize("xs,ys,n,k4", [(2560, 20, 9, 5), (3072, 16, 10, 6), (3840, 12, 7, 0), (5120, 12, 6, 5), (4608, 12, 6, 6),
-                                          (3072, 4, 5, 6), (2560, 4, 3, 5), (4096, 20, 12, 8), (2048, 24, 12, 8), (6144, 8, 5, 8),
-                                          (4096, 4, 5, 8), (2048, 4, 3, 8), (2048, 8, 300, 8)])
-def test_rows_of_several_supersteps(fpv, oracle, inverse_kernel, xs, ys, n, k4, res):
+@pytest.mark.parametrize("wide", ["1", "0"])
+@pytest.mark.parametrize("xs,ys,n,k4,k4n", [(2560, 20, 9, 10, 5), (3072, 16, 10, 12, 6), (3840, 12, 7, 0, 0), (5120, 12, 6, 10, 5), (4608, 12, 6, 6, 6),
+                                              (3072, 4, 5, 12, 6), (2560, 4, 3, 10, 5), (4096, 20, 12, 8, 0), (2048, 24, 12, 8, 0), (6144, 8, 5, 8, 6),
+                                              (4096, 4, 5, 8, 0), (2048, 4, 3, 8, 0), (2048, 8, 300, 8, 0)])
+def test_rows_of_several_supersteps(fpv, oracle, inverse_kernel, xs, ys, n, k4, k4n, res, wide):
     """Rows that are 2, 3 or 4 supersteps long: the three-wave kernel keeps the north operands in registers there too
     (m + 1 register sets taking turns; round 5) where the geometry's segment length, or the one below it, divides the
     row (2560 / 5120 wide: 20-pixel segments; 3072 / 4608: 24; 3840 wide divides by both and stays at 24 with the ring
     form: k4 = 0 here, either of the geometry's own lengths), for batches the chain bounds.  Rows that are a multiple of
-    2048 pixels (2048, 4096, 6144 wide) run 32-pixel segments (k4 = 8: instantiated for this form only, blocks of two);
-    300 frames of 2048 x 8: more workgroups than compute units.
+    2048 pixels (2048, 4096, 6144 wide) run 32-pixel segments (k4 = 8: instantiated for this form only, blocks of two),
+    1 or 2 times 2560 pixels 40-pixel segments (k4 = 10), 3072 wide 48 (k4 = 12); FPV_TRIO_WIDE=0: the lengths up to 24
+    only (k4n).  300 frames of 2048 x 8: more workgroups than compute units.
     Frames with about as many supersteps as a row has (four rows), superstep counts that are no multiple of m + 1 or of
     the block, flags of every kind, long identity runs; FPV_TRIO_RES=0: the same frames with the north bytes from the
     ring.  The superstep count of the batch tells which segment length ran."""
+    old_wide = os.environ.get("FPV_TRIO_WIDE")
+    os.environ["FPV_TRIO_WIDE"] = wide
+    if wide == "0":
+        k4 = k4n
     old = os.environ.get("FPV_TRIO_RES")
     if res == "0":
         os.environ["FPV_TRIO_RES"] = "0"
@@ -258,10 +264,11 @@ def test_rows_of_several_supersteps(fpv, oracle, inverse_kernel, xs, ys, n, k4, 
                 fits.append((steps == 0) if per_frame == 0 else (steps % per_frame == 0 and 1 <= steps // per_frame <= n))
             assert any(fits), (steps, res, k4, own)
     finally:
-        if old is None:
-            os.environ.pop("FPV_TRIO_RES", None)
-        else:
-            os.environ["FPV_TRIO_RES"] = old
+        for k, v in (("FPV_TRIO_RES", old), ("FPV_TRIO_WIDE", old_wide)):
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 def test_chain_simd_claim_fallback_and_recovery(fpv, oracle):

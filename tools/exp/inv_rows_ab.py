@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from __graft_entry__ import load_package
 ENVS = ({}, {"FPV_TRIO_WIDE": "0"}, {"FPV_TRIO_RES": "0"})
 pkg = load_package(); synth = importlib.import_module("fpv_amd.synth")
-for xs, ys, n, bits, shift in ((4096, 4096, 60, 16, 0), (4096, 4096, 8, 16, 0), (2048, 1536, 256, 12, 4), (2048, 1536, 512, 12, 4), (2048, 2048, 32, 16, 0), (2560, 2048, 128, 12, 4), (3072, 3072, 64, 16, 0), (1280, 800, 256, 12, 4)):
+for xs, ys, n, bits, shift in ((4096, 4096, 60, 16, 0), (4096, 4096, 8, 16, 0), (2048, 1536, 256, 12, 4), (2048, 1536, 512, 12, 4), (2048, 2048, 32, 16, 0), (2560, 2048, 128, 12, 4), (2560, 2048, 512, 12, 4), (3072, 3072, 64, 16, 0), (5120, 2880, 16, 16, 0), (1280, 800, 256, 12, 4)):
     base = synth.plasma_frames(9, xs, ys, bits=bits, seed=3)
     d = torch.from_numpy(base[1:].reshape(8, -1).view(np.int16)).cuda()
     fr = d[torch.arange(n, device="cuda") % 8].contiguous().view(torch.uint16)

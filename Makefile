@@ -31,7 +31,7 @@ all: product tools oracle shim refcli refcb columnar arrow
 
 product: $(LIBDIR)/libfpvhip.so $(LIBDIR)/libfpv_amd.so
 
-$(LIBDIR)/libfpvhip.so: $(CSRC)/fpv_kernels.hip $(CSRC)/fpv_tile.inc $(CSRC)/fpv_tile8.inc $(CSRC)/fpv_inverse.inc $(CSRC)/fpv_capi.hip $(CSRC)/fpv_kernels.h include/fpv_hip.h
+$(LIBDIR)/libfpvhip.so: $(CSRC)/fpv_kernels.hip $(CSRC)/fpv_tile.inc $(CSRC)/fpv_tile8.inc $(CSRC)/fpv_inverse.inc $(CSRC)/fpv_inv_pass.inc $(CSRC)/fpv_capi.hip $(CSRC)/fpv_kernels.h include/fpv_hip.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -shared $(CSRC)/fpv_kernels.hip $(CSRC)/fpv_capi.hip \
 	    -Wl,-rpath,$(ROCM_LIB) -o $@

@@ -1885,12 +1885,14 @@ static bool trio_ip_ok(const Geom& g, uint32_t k4) {  // a lane's north bytes mu
   const char* e = getenv("FPV_TRIO_INPLACE");  // read per launch: A/B runs and tests switch inside one process
   return !(e && atoi(e) == 0) && k4 && g.xs % (4 * k4) == 0;
 }
-// res (k_inverse_trio<K4, M, true, true>): the row is exactly one superstep long and the block length even -- north operands stay in
-// registers.  Taken for batches of up to 2.25 frames per CU -- where the chain wave is what a frame waits for: 32 ... 512 frames
-// -7 ... -10 %, 576 frames -3 %; from 640 frames on the batch is bound by HBM and the form costs 0 ... 1 % (profiles/r05_inverse_ab.log).
+// The register-north form (k_inverse_trio<K4, M, true, m>, m >= 1): the row is m supersteps long, so the bytes above a lane's
+// segment are pixels the same lane made m supersteps earlier -- they stay in registers (m + 1 sets taking turns).  Taken for
+// batches of up to 2.25 frames per CU -- where the chain wave is what a frame waits for: 1280 wide 32 ... 512 frames -7 ... -10 %,
+// 576 frames -3 %; from 640 frames on the batch is bound by HBM and the form costs 0 ... 1 % (profiles/r05_inverse_ab.log).
 // FPV_TRIO_RES (read per launch: A/B runs, tests): 0 never, 1 whatever the batch size.
-// Supersteps per row where the register-north form applies (0: it does not): rows of one superstep in blocks of an even
-// length, rows of 2 ... 4 supersteps (as many register sets + 1: 100 registers at most; segments of 20 or 24 pixels) in blocks of four.
+// trio_res_rows: supersteps per row where the form applies (0: it does not) -- rows of one superstep in blocks of an even
+// length; rows of 2 ... 4 supersteps at segments of 20 or 24 pixels in blocks of four (100 registers of sets at most); and the
+// segment lengths beyond the other forms' limit (32 / 40 / 48 pixels: trio_wide_rows) in blocks of two.
 static uint32_t trio_res_rows(const Geom& g, uint32_t k4, uint32_t mblk) {
   const uint32_t S = 256 * k4;
   if (g.xs % S) return 0;

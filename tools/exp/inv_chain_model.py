@@ -38,16 +38,20 @@ def seg(nv, dv, rv, win):           # one pass of every lane: win (64,), nv/dv/r
         out[:, k] = w
     return out
 worst = []
+nwrong_first = []
 for t in range((XS * YS - head) // S):
     s0 = head + t * S
     idx = s0 + np.arange(S).reshape(64, K)
     nv, nwv, rv = x[idx - XS], x[idx - XS - 1], R[idx]
     dv = nv - nwv
     wprev = x[s0 - 1]
-    inp = x[idx[:, 0] - 1 - XS].copy(); inp[0] = wprev       # guess: the pixel above the west neighbour
+    inp = x[idx[:, 0] - 1 - XS].copy()                       # guess: the pixel above the west neighbour
+    if os.environ.get("GUESS") == "nr": inp = (inp + R[idx[:, 0] - 1]) & 255   # ... + the west neighbour's own residual
+    inp[0] = wprev
+    nwrong_first.append(int((inp != np.concatenate([[wprev], x[idx[:-1, K - 1]]])).sum()))
     static = (dv == 0).all(axis=1); static[0] = False
-    log, npass = [], 0
-    hist = np.zeros(64, bool); dyn = np.full(64, optimist == 1); pin = np.zeros(64, np.int64); pout = np.zeros(64, np.int64)
+    log, errs, npass = [], [], 0
+    hist = np.zeros(64, bool); evid = np.zeros(64, bool); dyn = np.full(64, optimist in (1, 4)); memo = optimist in (3, 4); min_ = np.zeros(64, np.int64); mout = np.zeros(64, np.int64); mhave = np.zeros(64, bool); prev_in = None; prev_out = None; pin = np.zeros(64, np.int64); pout = np.zeros(64, np.int64)
     X = None
     while True:
         Xn = seg(nv, dv, rv, inp)
@@ -55,34 +59,51 @@ for t in range((XS * YS - head) // S):
         else: X = Xn
         npass += 1
         last = X[:, K - 1]
+        if memo and npass > 4 and prev_in is not None:       # the pair a lane had before its input last changed
+            chg = inp != prev_in
+            min_ = np.where(chg, prev_in, min_); mout = np.where(chg, prev_out, mout); mhave |= chg
+        prev_in, prev_out = inp.copy(), last.copy()
         if npass > 4:
             ch = hist & (inp != pin)
-            dyn = np.where(ch, ((last - pout) & 255) == ((inp - pin) & 255), dyn)
+            dyn = np.where(ch, ((last - pout) & 255) == ((inp - pin) & 255), dyn); evid |= ch
             upd = (~hist) | (inp != pin)
             pin = np.where(upd, inp, pin); pout = np.where(upd, last, pout); hist |= True
         pred = np.concatenate([[wprev], last[:-1]])
         bad = pred != inp
+        tin = np.concatenate([[x[s0 - 1]], x[idx[:-1, K - 1]]])
         log.append(np.flatnonzero(bad))
+        errs.append([(int(j), int(((inp[j] - tin[j] + 128) & 255) - 128), int(((last[j] - x[idx[j, K - 1]] + 128) & 255) - 128)) for j in np.flatnonzero((inp != tin) | (last != x[idx[:, K - 1]]))])
         if not bad.any() or npass > 70: break
         nxt = pred.copy()
         if optimist != -1 and npass >= 4 and npass < 28:
-            sh = static.copy() if optimist == -2 else (static | dyn); sh[0] = False
+            if optimist == 2:    # momentum: a lane without evidence believes what the nearest lane to its left with evidence showed
+                ev = evid.copy(); bel = dyn.copy()
+                for j in range(1, 64):
+                    if not ev[j]: bel[j] = bel[j - 1] if j > 1 else False
+                sh = static | bel
+            else:
+                sh = static.copy() if optimist == -2 else (static | dyn)
+            sh[0] = False
             isc = (~sh).astype(np.int64); v = np.where(sh, (last - inp) & 255, last)
             # inclusive segmented scan, sequential model
             for j in range(1, 64):
                 if not isc[j]:
                     v[j] = (v[j] + v[j - 1]) & 255; isc[j] = isc[j - 1]
             nxt = np.concatenate([[wprev], v[:-1]])
+            if memo:   # a lane proposed the input it had before answers with the output it had then; its right neighbour is proposed that
+                est = np.where(mhave & (nxt == min_), mout, np.where(nxt == inp, last, v))
+                nxt2 = np.concatenate([[wprev], est[:-1]])
+                nxt = np.where(np.concatenate([[False], (mhave & (nxt == min_))[:-1]]), nxt2, nxt)
         inp = nxt
-    worst.append((npass, t, log))
+    worst.append((npass, t, log, errs))
 worst.sort(key=lambda a: -a[0])
 hist_p = np.bincount([w[0] for w in worst])
-print(kind, "optimist", optimist, "total passes", sum(w[0] for w in worst), "passes histogram", {i: int(c) for i, c in enumerate(hist_p) if c})
-for npass, t, log in worst[:2]:
+print("wrong first guesses per superstep (of 63):", round(float(np.mean(nwrong_first)), 2)); print(kind, "optimist", optimist, "total passes", sum(w[0] for w in worst), "passes histogram", {i: int(c) for i, c in enumerate(hist_p) if c})
+for npass, t, log, errs in worst[:1]:
     print(f"superstep {t}: {npass} passes; wrong lanes after each pass:")
-    for p, l in enumerate(log[:45]): print(f"  pass {p + 1:2d}: {len(l):2d} wrong: {l.tolist()[:40]}")
+    for p, l in enumerate(log[:45]): print(f"  pass {p + 1:2d}: {len(l):2d} wrong: {l.tolist()[:24]}   (lane, input error, output error): {errs[p][:12]}")
 # the front of the worst superstep, lane by lane: what a lane's input / output were before and after the correction reached it
-npass, t, log = worst[0]
+npass, t, log, errs = worst[0]
 s0 = head + t * S
 idx = s0 + np.arange(S).reshape(64, K)
 nv, nwv, rv = x[idx - XS], x[idx - XS - 1], R[idx]
@@ -95,3 +116,12 @@ for j in range(20, 64):
     ot = seg(nv[j:j + 1], dv[j:j + 1], rv[j:j + 1], truth_in[j:j + 1])[0, K - 1]
     outs = [int(seg(nv[j:j + 1], dv[j:j + 1], rv[j:j + 1], np.array([(truth_in[j] + e) & 255]))[0, K - 1] - ot) for e in (-3, -2, -1, 0, 1, 2, 3)]
     print(f"  {j:2d}: {int(guess[j] - truth_in[j]):+d}  {int(og - ot):+d}  D!=0: {int((dv[j] != 0).sum())}  sum|r| {int(np.minimum(rv[j], 256 - rv[j]).sum())}   out(true+e)-out(true), e=-3..3: {outs}")
+j = 26
+w0 = truth_in[j]
+for e in (0, 1):
+    w = (w0 + e) & 255; tr = []
+    for k in range(K):
+        g = w + dv[j, k]; lo, hi = min(nv[j, k], w), max(nv[j, k], w)
+        w = (rv[j, k] + max(lo, min(hi, g))) & 255; tr.append(int(w))
+    print("lane 26, input", int((w0 + e) & 255), "->", tr)
+print("n :", nv[j].tolist()); print("d :", dv[j].tolist()); print("r :", rv[j].tolist())

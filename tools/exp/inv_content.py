@@ -5,6 +5,9 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from __graft_entry__ import load_package
 pkg = load_package(); synth = importlib.import_module("fpv_amd.synth")
+if os.environ.get("FPV_AB_LIB"):   # another build of the library (A/B of a kernel change by content)
+    import ctypes
+    lib = ctypes.CDLL(os.path.abspath(os.environ["FPV_AB_LIB"])); pkg._declare_hip(lib); pkg._hip = lib
 XS, YS = 1280, 800
 NP = XS * YS
 rng = np.random.default_rng(5)
@@ -22,7 +25,7 @@ for bits in (0, 2, 4, 6, 8):
 cases["1/f field + 4 bits of noise, 16-bit"] = (np.stack([np.clip(one_over_f(k) + rng.integers(0, 16, (YS, XS)), 0, 65535) for k in range(9)]).astype(np.uint16), 0)
 cases["uniform noise, 16-bit"] = (synth.noise_frames(9, XS, YS, seed=1), 0)
 for name, (base, shift) in cases.items():
-    for n in (256, 1000):
+    for n in ((256,) if os.environ.get("FPV_AB_LIB") else (256, 1000)):
         d = torch.from_numpy(base[1:].reshape(8, -1).view(np.int16)).cuda()
         fr = d[torch.arange(n, device="cuda") % 8].contiguous().view(torch.uint16)
         p = pkg.Predictor(XS, YS, shift, False, max_batch=n); p.set_delta_raw(base[0])

@@ -271,6 +271,33 @@ def test_rows_of_several_supersteps(fpv, oracle, inverse_kernel, xs, ys, n, k4, 
                 os.environ[k] = v
 
 
+def test_smooth_frames_do_not_cascade(fpv, oracle):
+    """Smooth frames with a delta frame: the delta planes hover around the 255 / 0 wrap, where the clamped gradient is a shift on
+    either side with a constant of its own -- a wrong guess is never forgotten, and under the plain rule its lane's wrong
+    output overwrites the right neighbour's right input, which hands a wrong output on: a glitch travelling a lane per pass
+    ahead of its fix, up to 60 passes per superstep (round 5 measured 51-58 on such frames).  The long-correction path's memo
+    (a lane proposed the input it had before answers with the output it had then) ends it where the fix meets it: the worst
+    superstep stays near the point where that path takes over.  Exact either way."""
+    import torch
+    xs, ys, n = 1280, 96, 6
+    yy, xx = np.mgrid[0:ys, 0:xs].astype(np.float32)
+    fr = np.stack([30000 + 9000 * np.sin(xx / (310.0 + 7 * k) + 0.3 * k) + 7000 * np.sin(yy / (270.0 - 5 * k) + 0.2 * k)
+                   + 5000 * np.sin((xx + yy) / (530.0 + 11 * k)) for k in range(n + 1)]).astype(np.uint16)
+    p = fpv.Predictor(xs, ys, 0, False, max_batch=n)
+    p.set_delta_raw(fr[0])
+    d = torch.from_numpy(fr[1:].reshape(n, -1).view(np.int16)).cuda().view(torch.uint16)
+    high, low, pv, flags = p.predict(d)
+    assert bool(((flags & 3) == 3).all()), flags.cpu().numpy()      # delta + clamped gradient: the case in question
+    p.set_delta_decoded(fr[0])
+    p.inverse_pass_stats(reset=True)
+    rec = p.inverse(high, low, flags)
+    torch.cuda.synchronize()
+    steps, passes = p.inverse_pass_stats()
+    assert np.array_equal(rec.cpu().view(torch.int16).numpy().view(np.uint16).reshape(n, ys, xs), fr[1:])
+    assert steps > 0 and passes / steps < 4.5 and p.last_pass_extremes[1] <= 20, (steps, passes, p.last_pass_extremes)
+    p.close()
+
+
 def test_chain_simd_claim_fallback_and_recovery(fpv, oracle):
     """The three-wave kernel's workgroups claim a SIMD that no other frame's chain wave is on, in a
     per-CU word of device memory -- a placement hint only.  With every SIMD marked taken (what a

@@ -9,11 +9,17 @@ pkg = load_package(); synth = importlib.import_module("fpv_amd.synth")
 from oracle.oracle import Oracle
 XS, YS, K = 1280, 800, 20
 kind = sys.argv[1] if len(sys.argv) > 1 else "sines"
+MEMO_FROM = int(os.environ.get('MEMO_FROM', '4'))   # the memo is kept from this pass on (4: the long-correction path only)
 optimist = int(sys.argv[2]) if len(sys.argv) > 2 else 1   # 1: lanes without evidence are shifts, 0: constants (dynamic evidence either way), -1: no scan (the plain rule), -2: static shifts only (round 3)
 if kind == "sines":
     yy, xx = np.mgrid[0:YS, 0:XS].astype(np.float32)
     def sines(k): return 30000 + 9000 * np.sin(xx / (310.0 + 7 * k) + 0.3 * k) + 7000 * np.sin(yy / (270.0 - 5 * k) + 0.2 * k) + 5000 * np.sin((xx + yy) / (530.0 + 11 * k))
     base = np.stack([np.clip(sines(k), 0, 65535) for k in range(2)]).astype(np.uint16); shift = 0
+elif kind == "dark":
+    rng = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:YS, 0:XS].astype(np.float32)
+    blobs = 3000 * np.exp(-((xx - 400) ** 2 + (yy - 300) ** 2) / 5000.0) + 1500 * np.exp(-((xx - 900) ** 2 + (yy - 500) ** 2) / 20000.0)
+    base = np.stack([np.clip(100 + blobs * (k > 0) + rng.normal(0, 4, (YS, XS)), 0, 4095) for k in range(2)]).astype(np.uint16); shift = 4
 else:
     base = synth.plasma_frames(2, XS, YS, bits=12, seed=7); shift = 4
 orc = Oracle()
@@ -59,7 +65,7 @@ for t in range((XS * YS - head) // S):
         else: X = Xn
         npass += 1
         last = X[:, K - 1]
-        if memo and npass > 4 and prev_in is not None:       # the pair a lane had before its input last changed
+        if memo and npass > MEMO_FROM and prev_in is not None:       # the pair a lane had before its input last changed
             chg = inp != prev_in
             min_ = np.where(chg, prev_in, min_); mout = np.where(chg, prev_out, mout); mhave |= chg
         prev_in, prev_out = inp.copy(), last.copy()
@@ -75,6 +81,11 @@ for t in range((XS * YS - head) // S):
         errs.append([(int(j), int(((inp[j] - tin[j] + 128) & 255) - 128), int(((last[j] - x[idx[j, K - 1]] + 128) & 255) - 128)) for j in np.flatnonzero((inp != tin) | (last != x[idx[:, K - 1]]))])
         if not bad.any() or npass > 70: break
         nxt = pred.copy()
+        if memo and MEMO_FROM < 4 and npass > MEMO_FROM and npass < (3 if os.environ.get('MEMO_ONCE') else 4):   # the memo alone behind the early passes (no scan yet); MEMO_ONCE: behind the second pass only
+            hitm = mhave & (nxt == min_); hitm[0] = False
+            est = np.where(hitm, mout, last)
+            nxt2 = np.concatenate([[wprev], est[:-1]])
+            nxt = np.where(np.concatenate([[False], hitm[:-1]]), nxt2, nxt)
         if optimist != -1 and npass >= 4 and npass < 28:
             if optimist == 2:    # momentum: a lane without evidence believes what the nearest lane to its left with evidence showed
                 ev = evid.copy(); bel = dyn.copy()

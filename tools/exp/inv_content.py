@@ -24,6 +24,14 @@ for bits in (0, 2, 4, 6, 8):
     cases[f"sines + {bits} bits of noise, 16-bit"] = (np.stack([np.clip(sines(k) + rng.integers(0, 1 << bits, (YS, XS)), 0, 65535) for k in range(9)]).astype(np.uint16), 0)
 cases["1/f field + 4 bits of noise, 16-bit"] = (np.stack([np.clip(one_over_f(k) + rng.integers(0, 16, (YS, XS)), 0, 65535) for k in range(9)]).astype(np.uint16), 0)
 cases["uniform noise, 16-bit"] = (synth.noise_frames(9, XS, YS, seed=1), 0)
+# a sensor looking at (nearly) nothing: a dark level plus noise, a few bright blobs; the delta frame is another such frame
+def dark(sigma, bits):
+    blobs = 3000 * np.exp(-((xx - 400) ** 2 + (yy - 300) ** 2) / 5000.0) + 1500 * np.exp(-((xx - 900) ** 2 + (yy - 500) ** 2) / 20000.0)
+    return np.stack([np.clip(100 + blobs * (k > 0) + rng.normal(0, sigma, (YS, XS)), 0, (1 << bits) - 1) for k in range(9)]).astype(np.uint16)
+for sigma in (1.5, 4, 12):
+    cases[f"dark sensor, sigma {sigma}, 12-bit (shift 4)"] = (dark(sigma, 12), 4)
+cases["dark sensor, sigma 20, 16-bit (shift 0)"] = (dark(20, 16), 0)
+if os.environ.get("CASES"): cases = {k: v for k, v in cases.items() if os.environ["CASES"] in k}
 for name, (base, shift) in cases.items():
     for n in ((256,) if os.environ.get("FPV_AB_LIB") else (256, 1000)):
         d = torch.from_numpy(base[1:].reshape(8, -1).view(np.int16)).cuda()

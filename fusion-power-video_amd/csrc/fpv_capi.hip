@@ -150,6 +150,12 @@ struct fpvhip_ctx {
   uint8_t* d_dlow = nullptr;
   uint16_t* d_dtmp = nullptr;  // upload buffer for set_delta_*
   uint32_t* d_inv_diag = nullptr;  // speculative inverse: supersteps, passes (diagnostics)
+  // The inverse's counters as they were behind the last launch that has finished (pinned; copied behind every launch, read without
+  // waiting) and what the last decision saw: a batch takes the kernel form with the memo behind the second pass when more than a
+  // sixteenth of the supersteps since then ran into the long-correction path (smooth frames, a dark sensor: fpv_inverse.inc).
+  volatile uint32_t* h_inv_diag = nullptr;
+  uint32_t inv_seen_steps = 0, inv_seen_long = 0;
+  bool inv_memo2 = false;
   bool have_delta = false;
   int timing_left = 3;  // FPV_TIMING: the first few batches are reported
   // workspace of the device-resident entry points
@@ -307,6 +313,12 @@ static fpvhip_ctx* create_impl(int device, const Geom& g, uint32_t max_batch,
     HIPOK(c, hipMalloc(reinterpret_cast<void**>(&c->d_dtmp), (size_t)g.npix * 2));
     HIPOK(c, hipMalloc(reinterpret_cast<void**>(&c->d_inv_diag), 64));
     HIPOK(c, hipMemset(c->d_inv_diag, 0, 64));
+    {
+      void* hp = nullptr;
+      HIPOK(c, hipHostMalloc(&hp, 64, hipHostMallocDefault));
+      memset(hp, 0, 64);
+      c->h_inv_diag = static_cast<volatile uint32_t*>(hp);
+    }
     if (g.fwd_ok) {
       HIPOK(c, hipMalloc(&c->d_ws, fpvhip::fwd_workspace_bytes(g, max_batch)));
       fpvhip::carve_fwd_workspace(g, max_batch, c->d_ws, &c->ws);
@@ -366,6 +378,7 @@ void fpvhip_destroy(fpvhip_ctx* c) {
   delete[] c->slots;
   give_stream(c->device, c->up); give_stream(c->device, c->comp); give_stream(c->device, c->down);
   hipFree(c->d_dhigh); hipFree(c->d_dlow); hipFree(c->d_dtmp); hipFree(c->d_ws); hipFree(c->d_inv_diag);
+  if (c->h_inv_diag) hipHostFree(const_cast<uint32_t*>(c->h_inv_diag));
   for (auto& e : c->ev) if (e) hipEventDestroy(e);
   delete c;
 }
@@ -577,6 +590,26 @@ int fpvhip_inverse_planes_submit(fpvhip_ctx* c, uint32_t slot, uint32_t nframes,
   return inverse_submit_impl(c, slot, nframes, flags, true);
 }
 
+
+// The hint for launch_inverse's memo2 form, from the counters the launches before left (never waits: what has not been copied back
+// yet counts next time), and the copy behind a launch.
+static bool inv_memo2_hint(fpvhip_ctx* c) {
+  if (!c->h_inv_diag) return false;
+  const uint32_t steps = c->h_inv_diag[0], lng = c->h_inv_diag[6];
+  if (steps < c->inv_seen_steps || lng < c->inv_seen_long) { c->inv_seen_steps = steps; c->inv_seen_long = lng; }  // the counters were reset
+  const uint32_t ds = steps - c->inv_seen_steps, dl = lng - c->inv_seen_long;
+  if (ds >= 256) {   // enough supersteps since the last decision
+    c->inv_memo2 = 16ull * dl > ds;
+    c->inv_seen_steps = steps;
+    c->inv_seen_long = lng;
+  }
+  return c->inv_memo2;
+}
+static hipError_t inv_diag_copy_back(fpvhip_ctx* c, hipStream_t s) {
+  if (!c->h_inv_diag) return hipSuccess;
+  return hipMemcpyAsync(const_cast<uint32_t*>(c->h_inv_diag), c->d_inv_diag, 32, hipMemcpyDeviceToHost, s);
+}
+
 static int inverse_submit_impl(fpvhip_ctx* c, uint32_t slot, uint32_t nframes,
                                const uint8_t* flags, bool to_planes, int unshift, int big_endian) {
   if (check_slot(c, slot)) return -1;
@@ -601,7 +634,8 @@ static int inverse_submit_impl(fpvhip_ctx* c, uint32_t slot, uint32_t nframes,
   HIPOK(c, fpvhip::launch_inverse(c->g, s.d_high, s.d_low,
                                   c->have_delta ? c->d_dhigh : nullptr,
                                   c->have_delta ? c->d_dlow : nullptr, s.d_flags,
-                                  nframes, s.d_pix, c->comp, c->d_inv_diag));
+                                  nframes, s.d_pix, c->comp, c->d_inv_diag, inv_memo2_hint(c)));
+  HIPOK(c, inv_diag_copy_back(c, c->comp));
   if (to_planes)  // (pixel >> 8, pixel & 0xff) back into the plane staging buffers
     HIPOK(c, fpvhip::launch_split_planes(s.d_pix, s.d_high, s.d_low, nframes * np, c->comp));
   else if (unshift >= 0)  // UnextractFrame (cc:850-862) fused in front of the copy back
@@ -659,7 +693,8 @@ int fpvhip_inverse_device(fpvhip_ctx* c, const void* d_high, const void* d_low,
                c->have_delta ? c->d_dhigh : nullptr,
                c->have_delta ? c->d_dlow : nullptr,
                static_cast<const uint8_t*>(d_flags), nframes,
-               static_cast<uint16_t*>(d_frames), static_cast<hipStream_t>(stream), c->d_inv_diag));
+               static_cast<uint16_t*>(d_frames), static_cast<hipStream_t>(stream), c->d_inv_diag, inv_memo2_hint(c)));
+  HIPOK(c, inv_diag_copy_back(c, static_cast<hipStream_t>(stream)));
   return 0;
 }
 

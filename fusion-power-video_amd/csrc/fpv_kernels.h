@@ -108,13 +108,15 @@ hipError_t launch_predict(const Geom& g, const uint16_t* d_frames,
                           uint8_t* d_flags, hipStream_t s, hipEvent_t* ev);
 
 // Inverse predictor.  d_dhigh/d_dlow: delta planes or null.  d_diag, when not
-// null, points to two dwords the speculative kernel adds its superstep and pass
-// counts to (diagnostics).
+// null, points to 16 dwords the speculative kernels add their counts to: [0] supersteps,
+// [1] passes, [2] / [3] maxima, [6] supersteps that went into the long-correction path.
+// memo2_hint: take the three-wave kernel's form with the memo behind the second pass (frames
+// whose corrections travel: see fpv_inverse.inc) where one is instantiated.
 hipError_t launch_inverse(const Geom& g, const uint8_t* d_high,
                           const uint8_t* d_low, const uint8_t* d_dhigh,
                           const uint8_t* d_dlow, const uint8_t* d_flags,
                           uint32_t nframes, uint16_t* d_frames, hipStream_t s,
-                          uint32_t* d_diag = nullptr);
+                          uint32_t* d_diag = nullptr, bool memo2_hint = false);
 
 // Overwrites the per-CU "SIMDs running a chain wave" words of the three-wave inverse (current device).
 hipError_t set_chain_simd_mask(uint32_t value);

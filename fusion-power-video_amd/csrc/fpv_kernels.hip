@@ -1910,7 +1910,15 @@ static uint32_t trio_res_ok(const Geom& g, uint32_t k4, uint32_t mblk, uint32_t 
 }
 // The instantiation for (in place?, register-north form: supersteps per row, 0 = not)
 template <int K4, int MB>
-static auto trio_kernel(bool ip, uint32_t res) -> decltype(&k_inverse_trio<K4, MB, true, 1>) {
+static auto trio_kernel(bool ip, uint32_t res, bool m2 = false) -> decltype(&k_inverse_trio<K4, MB, true, 1>) {
+  // the memo behind the second pass (M2: its own instantiations, fpv_inverse.inc): the register-north forms of one superstep per row
+  // in blocks of four, and the long segments' -- the batches the chain wave bounds
+  if constexpr ((K4 > (int)kSpecMaxK4 && MB == 2) || (K4 <= (int)kSpecMaxK4 && MB == 4)) {
+    if (m2 && ip && res == 1) return &k_inverse_trio<K4, MB, true, 1, true>;
+    if constexpr (K4 > (int)kSpecMaxK4 && trio_wide_rows(K4) >= 2) {
+      if (m2 && ip && res == 2) return &k_inverse_trio<K4, MB, true, 2, true>;
+    }
+  }
   if constexpr (K4 > (int)kSpecMaxK4) {   // the register-north forms only
     if constexpr (trio_wide_rows(K4) >= 2) {
       if (res == 2) return &k_inverse_trio<K4, MB, true, 2>;
@@ -2078,8 +2086,12 @@ hipError_t launch_inverse(const Geom& g, const uint8_t* d_high,
                           const uint8_t* d_low, const uint8_t* d_dhigh,
                           const uint8_t* d_dlow, const uint8_t* d_flags,
                           uint32_t nframes, uint16_t* d_frames, hipStream_t s,
-                          uint32_t* d_diag) {
+                          uint32_t* d_diag, bool memo2_hint) {
   prepare_kernels();
+  // The memo behind the second pass (k_inverse_trio<..., M2>): the caller's hint (fpv_capi.hip: the share of supersteps that ran
+  // into the long-correction path in the batches before); FPV_TRIO_MEMO2 = 0 / 1 (read per launch: tests, A/B runs) never / always.
+  bool memo2 = memo2_hint;
+  if (const char* e = getenv("FPV_TRIO_MEMO2")) memo2 = atoi(e) != 0;
   // FPV_INVERSE = auto (default) | trio | spec | fast | slow selects the kernel (tests, A/B timing).
   // auto: three waves per frame (shorter serial path per frame: 0.62 ms for a lone 1280x800
   // frame, 0.90 ms for 1000 of them) as long as every frame's workgroup is resident at once,
@@ -2102,7 +2114,7 @@ hipError_t launch_inverse(const Geom& g, const uint8_t* d_high,
 #endif
 #define FPV_LAUNCH_TRIO(K4, MB)                                                                       \
   if (k4 == K4 && mblk == MB) {                                                                       \
-    const auto kfn = trio_kernel<K4, MB>(ip, K4 > 6 ? trio_res_rows(g, K4, MB) : ip ? trio_res_ok(g, K4, MB, nframes) : 0u); \
+    const auto kfn = trio_kernel<K4, MB>(ip, K4 > 6 ? trio_res_rows(g, K4, MB) : ip ? trio_res_ok(g, K4, MB, nframes) : 0u, memo2); \
     kfn<<<nframes, 192, trio_lds(g, K4, MB, ip), s>>>(d_high, d_low, d_dhigh, d_dlow, d_flags, d_frames, FPV_TRIO_GEOM, \
                                                       trio_ring(g, K4, MB, ip), d_diag);             \
   }

@@ -79,6 +79,9 @@ while time.time() - t0 < budget:
     if rng.integers(0, 3):    # (unset: the library's own choice, which alone takes the 32-pixel segments)
         os.environ["FPV_TRIO_BLOCK"] = str(rng.choice(["1", "2", "4"]))
     os.environ["FPV_TRIO_INPLACE"] = str(rng.choice(["1", "0"], p=[0.7, 0.3]))
+    os.environ.pop("FPV_TRIO_MEMO2", None)
+    if rng.integers(0, 2):   # the three-wave kernel's form with the memo behind the second pass (unset: the library's choice from the batches before)
+        os.environ["FPV_TRIO_MEMO2"] = str(rng.choice(["1", "0"]))
     os.environ["FPV_TRIO_WIDE"] = str(rng.choice(["1", "0"], p=[0.8, 0.2]))   # 32-pixel segments on rows that are multiples of 2048 pixels (auto kernel choice only)
     os.environ["FPV_TRIO_RES"] = str(rng.choice(["1", "0"], p=[0.7, 0.3]))   # north operands in registers where the row is one superstep long (256, 1280, 1536 wide here)
     # forward path (read when the context is created): the tile pass with a random tile height where the

@@ -271,13 +271,33 @@ def test_rows_of_several_supersteps(fpv, oracle, inverse_kernel, xs, ys, n, k4, 
                 os.environ[k] = v
 
 
-def test_smooth_frames_do_not_cascade(fpv, oracle):
+@pytest.mark.parametrize("memo2", ["auto", "1", "0"])
+def test_smooth_frames_do_not_cascade(fpv, oracle, inverse_kernel, memo2):
     """Smooth frames with a delta frame: the delta planes hover around the 255 / 0 wrap, where the clamped gradient is a shift on
     either side with a constant of its own -- a wrong guess is never forgotten, and under the plain rule its lane's wrong
     output overwrites the right neighbour's right input, which hands a wrong output on: a glitch travelling a lane per pass
     ahead of its fix, up to 60 passes per superstep (round 5 measured 51-58 on such frames).  The long-correction path's memo
     (a lane proposed the input it had before answers with the output it had then) ends it where the fix meets it: the worst
-    superstep stays near the point where that path takes over.  Exact either way."""
+    superstep stays near the point where that path takes over.  Exact either way.
+    The three-wave kernel has a second form with such a memo already behind the second pass (FPV_TRIO_MEMO2=1 / 0: always /
+    never); left alone, the library takes it for a batch when more than a sixteenth of the supersteps of the batches
+    before went into the long-correction path: here from the second launch on, with fewer passes than the first."""
+    import torch
+    old_m2 = os.environ.get("FPV_TRIO_MEMO2")
+    if memo2 == "auto":
+        os.environ.pop("FPV_TRIO_MEMO2", None)
+    else:
+        os.environ["FPV_TRIO_MEMO2"] = memo2
+    try:
+        _smooth_case(fpv, inverse_kernel, memo2)
+    finally:
+        if old_m2 is None:
+            os.environ.pop("FPV_TRIO_MEMO2", None)
+        else:
+            os.environ["FPV_TRIO_MEMO2"] = old_m2
+
+
+def _smooth_case(fpv, inverse_kernel, memo2):
     import torch
     xs, ys, n = 1280, 96, 6
     yy, xx = np.mgrid[0:ys, 0:xs].astype(np.float32)
@@ -295,6 +315,19 @@ def test_smooth_frames_do_not_cascade(fpv, oracle):
     steps, passes = p.inverse_pass_stats()
     assert np.array_equal(rec.cpu().view(torch.int16).numpy().view(np.uint16).reshape(n, ys, xs), fr[1:])
     assert steps > 0 and passes / steps < 4.5 and p.last_pass_extremes[1] <= 20, (steps, passes, p.last_pass_extremes)
+    # a second and a third launch of the same batch: the counters of the launch before have come back by then
+    per_launch = [passes / steps]
+    for _ in range(2):
+        p.inverse_pass_stats(reset=True)
+        rec = p.inverse(high, low, flags)
+        torch.cuda.synchronize()
+        s2, p2 = p.inverse_pass_stats()
+        assert np.array_equal(rec.cpu().view(torch.int16).numpy().view(np.uint16).reshape(n, ys, xs), fr[1:])
+        per_launch.append(p2 / s2)
+    if inverse_kernel == "trio" and memo2 == "auto":
+        assert per_launch[2] < per_launch[0] - 0.1, per_launch      # the memo form took over
+    if inverse_kernel == "trio" and memo2 == "0":
+        assert abs(per_launch[2] - per_launch[0]) < 1e-9, per_launch
     p.close()
 
 

@@ -51,12 +51,17 @@ def test_no_kernel_spills_and_register_budgets_hold(tmp_path):
     # supersteps at the geometry's own segment length); round 4's choice k_inverse_trio<4, 4> (both forms) stays within 128
     # (<5, 2, true, RES>: both the form that reads its north bytes from the ring and the one that keeps them in registers; the
     # latter in blocks of four, <5, 4, true, true>, is what partial batches take: three workgroups per CU are enough there)
-    k52 = [k for n, k in ks.items() if "k_inverse_trioILi5ELi2ELb1E" in n]
-    assert len(k52) == 2 and all(k["vgpr_count"] + k["agpr_count"] <= 168 for k in k52), k52
-    k54 = [k for n, k in ks.items() if "k_inverse_trioILi5ELi4ELb1ELi1E" in n]
-    assert len(k54) == 1 and k54[0]["vgpr_count"] + k54[0]["agpr_count"] <= 168, k54
-    k44 = [k for n, k in ks.items() if "k_inverse_trioILi4ELi4ELb" in n and ("ELi0EEE" in n or "ELi1EEE" in n)]
-    assert len(k44) == 3 and all(k["vgpr_count"] + k["agpr_count"] <= 128 for k in k44), k44
-    # rows of 2 ... 4 supersteps (m + 1 register sets): partial batches only, at most two workgroups per CU -- no spills
-    multi = [k for n, k in ks.items() if "k_inverse_trioILi" in n and any(f"ELb1ELi{m}EEE" in n for m in (2, 3, 4))]
-    assert len(multi) == 8 and all(k["vgpr_count"] + k["agpr_count"] <= 256 and k.get("vgpr_spill_count", 0) == 0 for k in multi), multi
+    trio = {}
+    for n, k in ks.items():   # k_inverse_trio<K4, M, IP, RES, M2>
+        m = re.search(r"k_inverse_trioILi(\d+)ELi(\d+)ELb([01])ELi(\d+)ELb([01])E", n)
+        if m:
+            trio[tuple(int(v) for v in m.groups())] = k["vgpr_count"] + k["agpr_count"]
+    assert trio[(5, 2, 1, 0, 0)] <= 168 and trio[(5, 2, 1, 1, 0)] <= 168, trio
+    assert trio[(5, 4, 1, 1, 0)] <= 168, trio
+    assert all(trio[(4, 4, ip, res, 0)] <= 128 for ip, res in ((0, 0), (1, 0), (1, 1))), trio
+    # rows of 2 ... 4 supersteps (m + 1 register sets), the long segments (32 / 40 / 48 pixels per lane) and the forms with the memo
+    # behind the second pass: partial batches only, at most two workgroups per CU -- no spills (checked above), registers within the file
+    multi = [v for (k4, mb, ip, res, m2), v in trio.items() if res >= 2 and not m2]
+    memo2 = [v for (k4, mb, ip, res, m2), v in trio.items() if m2]
+    assert len(multi) == 8 and max(multi) <= 256, trio
+    assert len(memo2) == 11 and max(memo2) <= 256, trio

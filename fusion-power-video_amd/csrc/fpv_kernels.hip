@@ -1913,6 +1913,9 @@ template <int K4, int MB>
 static auto trio_kernel(bool ip, uint32_t res, bool m2 = false) -> decltype(&k_inverse_trio<K4, MB, true, 1>) {
   // the memo behind the second pass (M2: its own instantiations, fpv_inverse.inc): the register-north forms of one superstep per row
   // in blocks of four, and the long segments' -- the batches the chain wave bounds
+  if constexpr (K4 >= 4 && K4 <= (int)kSpecMaxK4 && (MB == 2 || MB == 4)) {   // ... and the ring form of the usual segment lengths (full batches, 1920 wide)
+    if (m2 && ip && res == 0) return &k_inverse_trio<K4, MB, true, 0, true>;
+  }
   if constexpr ((K4 > (int)kSpecMaxK4 && MB == 2) || (K4 <= (int)kSpecMaxK4 && MB == 4)) {
     if (m2 && ip && res == 1) return &k_inverse_trio<K4, MB, true, 1, true>;
     if constexpr (K4 > (int)kSpecMaxK4 && trio_wide_rows(K4) >= 2) {

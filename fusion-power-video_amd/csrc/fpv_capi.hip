@@ -606,7 +606,7 @@ static bool inv_memo2_hint(fpvhip_ctx* c) {
   return c->inv_memo2;
 }
 static hipError_t inv_diag_copy_back(fpvhip_ctx* c, hipStream_t s) {
-  if (!c->h_inv_diag) return hipSuccess;
+  if (!c->h_inv_diag || getenv("FPV_TRIO_MEMO2")) return hipSuccess;   // (forced either way: nothing to decide)
   return hipMemcpyAsync(const_cast<uint32_t*>(c->h_inv_diag), c->d_inv_diag, 32, hipMemcpyDeviceToHost, s);
 }
 

@@ -607,6 +607,42 @@ def main():
                         "sits on the latency of one frame's chain (smaller_batches: the time per batch hardly moves), so the GPU time per frame "
                         "falls with the batch size -- and stays 20-30x below the host's Brotli time per frame (6 ms per frame and thread) "
                         "even at 32, which is why the default stays where the pinned memory is small"}
+        if not args.quick:
+            # the same kernel on other CONTENTS (256 frames: the chain bounds the batch): the passes a superstep needs depend on it.  A dark
+            # sensor (dark level + noise against a delta frame of the same kind: the high byte of the difference is a mix of 0 and 255) and
+            # smooth frames keep wrong guesses alive -- the long-correction path's memo and, from the second launch on, the memo form of the
+            # kernel are for them (DESIGN.md section 4 "Smooth frames")
+            try:
+                rngc = np.random.default_rng(5)
+                gy, gx = np.mgrid[0:YS, 0:XS].astype(np.float32)
+                blobs = 3000 * np.exp(-((gx - 400) ** 2 + (gy - 300) ** 2) / 5000.0) + 1500 * np.exp(-((gx - 900) ** 2 + (gy - 500) ** 2) / 20000.0)
+                contents = {
+                    "dark_sensor_sigma4_12bit": (np.stack([np.clip(100 + blobs * (k > 0) + rngc.normal(0, 4, (YS, XS)), 0, 4095) for k in range(9)]).astype(np.uint16), 4),
+                    "smooth_sines_16bit": (np.stack([np.clip(30000 + 9000 * np.sin(gx / (310.0 + 7 * k) + 0.3 * k) + 7000 * np.sin(gy / (270.0 - 5 * k) + 0.2 * k)
+                                                             + 5000 * np.sin((gx + gy) / (530.0 + 11 * k)), 0, 65535) for k in range(9)]).astype(np.uint16), 0)}
+                byc, mc = {}, 256
+                for cname, (cb, cshift) in contents.items():
+                    pc = pkg.Predictor(XS, YS, cshift, False, max_batch=mc, slots=0, device=local_rank)
+                    pc.set_delta_raw(cb[0])
+                    dc = torch.from_numpy(cb[1:].reshape(8, -1).view(np.int16)).to(dev)
+                    frc = dc[torch.arange(mc, device=dev) % 8].contiguous().view(torch.uint16)
+                    plc = pc.predict(frc)
+                    torch.cuda.synchronize()
+                    pc.set_delta_decoded((cb[0].astype(np.uint16) << cshift).astype(np.uint16))
+                    pc.inverse_pass_stats(reset=True)
+                    pc.inverse(plc[0], plc[1], plc[3], out=rec[:mc])
+                    torch.cuda.synchronize()
+                    stc = pc.inverse_pass_stats()
+                    okc = bool((rec[:mc].view(torch.int16) == (frc.view(torch.int16).view(mc, NPIX) << cshift)).all())
+                    msc = min(pc.time_inverse(plc[0], plc[1], plc[3], rec[:mc], 20) / 20 for _ in range(2))
+                    byc[cname] = {"frames": mc, "ms_per_batch": round(msc, 4), "passes_per_superstep_first_launch": round(stc[1] / max(stc[0], 1), 3),
+                                  "most_passes_in_one_superstep": int(pc.last_pass_extremes[1]), "roundtrip_bit_exact": okc}
+                    pc.close()
+                    del dc, frc, plc
+                byc["plasma_256"] = sub.get("256", {}).get("ms_per_batch")
+                inv["by_content"] = byc
+            except Exception as e:   # a secondary figure: reported, never fatal
+                inv["by_content"] = {"error": f"{type(e).__name__}: {e}"[:200]}
         if psamp is not None:
             try:
                 power = power_phase(psamp, (("forward", lambda: pred.time_predict(d_frames, out, 20) / 20),

@@ -66,6 +66,8 @@ def test_bench_line_contract():
         assert k in cb, k
     assert cb["kind"] in ("reference", "port") and cb["cores"] == 1 and cb["value"] > 0
     assert d["inverse"]["roundtrip_bit_exact"] is True
+    bc = d["inverse"]["by_content"]
+    assert "error" not in bc and all(bc[k]["roundtrip_bit_exact"] and bc[k]["most_passes_in_one_superstep"] <= 40 for k in ("dark_sensor_sigma4_12bit", "smooth_sines_16bit")), bc
     # the power block: present whatever the box offers; where rocm-smi is there, each loop has its samples, and a loaded chip
     # draws more than an idle one
     pw = d["power"]

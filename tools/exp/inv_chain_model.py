@@ -102,9 +102,11 @@ for t in range((XS * YS - head) // S):
                     v[j] = (v[j] + v[j - 1]) & 255; isc[j] = isc[j - 1]
             nxt = np.concatenate([[wprev], v[:-1]])
             if memo:   # a lane proposed the input it had before answers with the output it had then; its right neighbour is proposed that
-                est = np.where(mhave & (nxt == min_), mout, np.where(nxt == inp, last, v))
-                nxt2 = np.concatenate([[wprev], est[:-1]])
-                nxt = np.where(np.concatenate([[False], (mhave & (nxt == min_))[:-1]]), nxt2, nxt)
+                for _ in range(int(os.environ.get("MEMO_ITERS", "1"))):   # (iterated: a memo hit's own right neighbour may hit its memo in turn)
+                    hitm = mhave & (nxt == min_)
+                    est = np.where(hitm, mout, np.where(nxt == inp, last, v))
+                    nxt2 = np.concatenate([[wprev], est[:-1]])
+                    nxt = np.where(np.concatenate([[False], hitm[:-1]]), nxt2, nxt)
         inp = nxt
     worst.append((npass, t, log, errs))
 worst.sort(key=lambda a: -a[0])

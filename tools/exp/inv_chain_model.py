@@ -15,6 +15,16 @@ if kind == "sines":
     yy, xx = np.mgrid[0:YS, 0:XS].astype(np.float32)
     def sines(k): return 30000 + 9000 * np.sin(xx / (310.0 + 7 * k) + 0.3 * k) + 7000 * np.sin(yy / (270.0 - 5 * k) + 0.2 * k) + 5000 * np.sin((xx + yy) / (530.0 + 11 * k))
     base = np.stack([np.clip(sines(k), 0, 65535) for k in range(2)]).astype(np.uint16); shift = 0
+elif kind.startswith("sines+"):    # sines + n bits of noise
+    rng = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:YS, 0:XS].astype(np.float32)
+    def sines(k): return 30000 + 9000 * np.sin(xx / (310.0 + 7 * k) + 0.3 * k) + 7000 * np.sin(yy / (270.0 - 5 * k) + 0.2 * k) + 5000 * np.sin((xx + yy) / (530.0 + 11 * k))
+    base = np.stack([np.clip(sines(k) + rng.integers(0, 1 << int(kind[6:]), (YS, XS)), 0, 65535) for k in range(2)]).astype(np.uint16); shift = 0
+elif kind.startswith("dark") and len(kind) > 4:   # dark<sigma>
+    rng = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:YS, 0:XS].astype(np.float32)
+    blobs = 3000 * np.exp(-((xx - 400) ** 2 + (yy - 300) ** 2) / 5000.0) + 1500 * np.exp(-((xx - 900) ** 2 + (yy - 500) ** 2) / 20000.0)
+    base = np.stack([np.clip(100 + blobs * (k > 0) + rng.normal(0, float(kind[4:]), (YS, XS)), 0, 4095) for k in range(2)]).astype(np.uint16); shift = 4
 elif kind == "dark":
     rng = np.random.default_rng(5)
     yy, xx = np.mgrid[0:YS, 0:XS].astype(np.float32)
@@ -111,7 +121,7 @@ for t in range((XS * YS - head) // S):
     worst.append((npass, t, log, errs))
 worst.sort(key=lambda a: -a[0])
 hist_p = np.bincount([w[0] for w in worst])
-print("wrong first guesses per superstep (of 63):", round(float(np.mean(nwrong_first)), 2)); print(kind, "optimist", optimist, "total passes", sum(w[0] for w in worst), "passes histogram", {i: int(c) for i, c in enumerate(hist_p) if c})
+print("wrong first guesses per superstep (of 63):", round(float(np.mean(nwrong_first)), 2)); print("share of supersteps in the long-correction path (5 passes and more):", round(sum(1 for w in worst if w[0] >= 5) / len(worst), 3)); print(kind, "optimist", optimist, "total passes", sum(w[0] for w in worst), "passes histogram", {i: int(c) for i, c in enumerate(hist_p) if c})
 for npass, t, log, errs in worst[:1]:
     print(f"superstep {t}: {npass} passes; wrong lanes after each pass:")
     for p, l in enumerate(log[:45]): print(f"  pass {p + 1:2d}: {len(l):2d} wrong: {l.tolist()[:24]}   (lane, input error, output error): {errs[p][:12]}")
